@@ -1,0 +1,9 @@
+"""MI355X-native 3D Gaussian Splatting rasteriser: drop-in for the hot-path functions of
+AubreyFeldker/gaussian-splatting (forward_pass / match_gaus_to_tiles / gpu_rasterize / c_rasterize
+/ rasterize / backward_pass / setup_gpu), backed by hand-written gfx950 HIP kernels behind the C
+ABI in include/gsplat.h.  The directory name is not a Python identifier: import it through the
+`gsplat_amd` alias module at the repo root (or importlib.import_module("gaussian-splatting_amd"))."""
+from ._lib import GsError, LIB_PATH, SIGNATURES, load as load_library   # noqa: F401
+from .api import (DeviceContext, GaussianSet, KernelLibrary, TileBinning, backward_pass, c_rasterize,   # noqa: F401
+                  forward_pass, gpu_rasterize, match_gaus_to_tiles, rasterize, setup_gpu)
+from .pipeline import FlatGrads, SplatPipeline, View, shard_views, train_step   # noqa: F401

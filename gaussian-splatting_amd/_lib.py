@@ -1,0 +1,71 @@
+"""ctypes binding of libgsplat_hip.so (include/gsplat.h).  Fails loudly when the library is
+missing: there is no CPU fallback in the product path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+
+
+class GsCamera(ctypes.Structure):
+    _fields_ = [("R", ctypes.c_double * 9), ("t", ctypes.c_double * 3),
+                ("fx", ctypes.c_double), ("fy", ctypes.c_double),
+                ("cam_width", ctypes.c_int32), ("cam_height", ctypes.c_int32),
+                ("res_w", ctypes.c_int32), ("res_h", ctypes.c_int32),
+                ("tile_size", ctypes.c_int32), ("sh_degree", ctypes.c_int32)]
+
+
+class GsError(RuntimeError):
+    pass
+
+
+_P = ctypes.c_void_p
+_I32 = ctypes.c_int32
+_I64 = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> (restype, argtypes); every symbol include/gsplat.h declares
+SIGNATURES = {
+    "gs_ctx_create": (ctypes.c_int, [ctypes.c_int, _P, ctypes.POINTER(_P)]),
+    "gs_ctx_set_stream": (ctypes.c_int, [_P, _P]),
+    "gs_ctx_destroy": (ctypes.c_int, [_P]),
+    "gs_ctx_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, _I32]),
+    "gs_last_error": (ctypes.c_char_p, []),
+    "gs_version": (ctypes.c_int, []),
+    "gs_preprocess": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, ctypes.POINTER(GsCamera)] + [_P] * 13),
+    "gs_bin_count": (ctypes.c_int, [_P, _I32, _P, _P, _I32, _I32, _I32, ctypes.POINTER(_I64)]),
+    "gs_bin_fill": (ctypes.c_int, [_P, _I32, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P]),
+    "gs_blend_forward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),
+                                        _I32, _I32, _I32, _F, _P, _P, _P]),
+    "gs_blend_backward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),
+                                         _I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_backward_params": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, ctypes.POINTER(GsCamera), _P, _P, _P,
+                                          _P, _P, _I32, _P, _P, _P, _P]),
+    "rasterize_tile": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GsError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gs_last_error()
+        raise GsError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,472 @@
+"""Host-side mirror of the reference's hot-path interface, backed by libgsplat_hip.so.
+
+Same names, positional order, defaults and return tuples as the reference:
+
+    setup_gpu()                                                   setup_gpu.py:3,370
+    forward_pass(ctx, queue, program, camera, camera_r, camera_t, gaussians,
+                 result_size, tile_size, training)                forward_pass.py:25,134,136
+    match_gaus_to_tiles(ctx, queue, program, tiles_touched, radiis, depths,
+                 result_size, tile_size)                          rasterization.py:6
+    gpu_rasterize(ctx, queue, program, centers, colors, opacities, conics, mapped_keys,
+                 training, result_size, tile_size, background_color)   rasterization.py:27,105-107
+    c_rasterize(...) / rasterize(...)                             rasterization.py:109,155
+    backward_pass(ctx, queue, program, camera, camera_r, camera_t, gaussians, radii, covs_2d,
+                 covs_3d, ws, ms, ts, dirs, clampeds, d_colors, d_2d_centers, d_conics)
+                                                                  backward_pass.py:19,68
+    GaussianSet(centers, shs, scales, rots, opacities, degrees)   gaussian.py:31-37
+
+Arrays may be NumPy (copied to the device; results come back as NumPy with the reference's dtypes)
+or torch CUDA tensors (zero-copy; results are torch tensors that stay on the device).  There is no
+CPU fallback: every function raises if the HIP library or a GPU is missing.
+
+Extensions the reference lacks (all keyword-only, defaults keep the reference behaviour):
+  gpu_rasterize(..., dL_dimage=None, pixel_offset=0.5)   explicit loss gradient (defect B4)
+  backward_pass(..., result_size=[979,546], tile_size=16) needed because forward intermediates
+                                                          are recomputed instead of re-read
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GsCamera, GsError, check
+
+TILE = 16
+
+
+# --------------------------------------------------------------------------- context
+class DeviceContext:
+    """Replaces the (ctx, queue, program) triple of setup_gpu() (setup_gpu.py:3-6,370): device id
+    + HIP stream + workspace arena owned by the native library."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise GsError("no HIP device visible: the MI355X path has no CPU fallback")
+        self.lib = _lib.load()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device)
+        torch.cuda.init()
+        self._stream_id = int(torch.cuda.current_stream(self.device).cuda_stream)
+        h = ctypes.c_void_p()
+        check(self.lib.gs_ctx_create(self.device_index, ctypes.c_void_p(self._stream_id), ctypes.byref(h)),
+              "gs_ctx_create")
+        self.handle = h
+
+    def sync_stream(self):
+        """Make the native ctx launch on torch's current stream for this device."""
+        sid = int(torch.cuda.current_stream(self.device).cuda_stream)
+        if sid != self._stream_id:
+            check(self.lib.gs_ctx_set_stream(self.handle, ctypes.c_void_p(sid)), "gs_ctx_set_stream")
+            self._stream_id = sid
+
+    def set_option(self, name, value):
+        check(self.lib.gs_ctx_set_option(self.handle, name.encode(), int(value)), "gs_ctx_set_option")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gs_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KernelLibrary:
+    """Stands in the `program` slot (the reference's built cl.Program); names the entry points."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.kernels = ("gs_preprocess", "gs_bin_count", "gs_bin_fill", "gs_blend_forward",
+                        "gs_blend_backward", "gs_backward_params", "rasterize_tile")
+
+
+_default_ctx = {}
+
+
+def setup_gpu(device=None):
+    """setup_gpu.py:3-6,370 -> (ctx, queue, program).  `queue` is the torch stream the kernels
+    are launched on; `program` names the native entry points."""
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    ctx = DeviceContext(device)
+    return ctx, torch.cuda.current_stream(ctx.device), KernelLibrary(ctx.lib)
+
+
+def _ctx(ctx):
+    if isinstance(ctx, DeviceContext):
+        return ctx
+    if ctx is not None:
+        raise TypeError("ctx must be the DeviceContext returned by setup_gpu() (or None)")
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if dev not in _default_ctx:
+        _default_ctx[dev] = DeviceContext(dev)
+    return _default_ctx[dev]
+
+
+# --------------------------------------------------------------------------- helpers
+_NP = {torch.float32: np.float32, torch.int32: np.int32, torch.uint8: np.uint8, torch.int64: np.int64}
+
+
+def _is_t(x):
+    return isinstance(x, torch.Tensor)
+
+
+def _dev(x, dtype, device, shape=None):
+    """NumPy array / torch tensor -> contiguous device tensor of `dtype`."""
+    if _is_t(x):
+        t = x.to(device=device, dtype=dtype)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=_NP[dtype])).to(device)
+    if shape is not None:
+        t = t.reshape(shape)
+    return t.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _np_out(t, dtype):
+    return t.detach().cpu().numpy().astype(dtype)
+
+
+def make_camera(camera, camera_r, camera_t, result_size, tile_size, degrees):
+    c = GsCamera()
+    r = np.asarray(camera_r.detach().cpu() if _is_t(camera_r) else camera_r, dtype=np.float64).reshape(3, 3)
+    t = np.asarray(camera_t.detach().cpu() if _is_t(camera_t) else camera_t, dtype=np.float64).reshape(3)
+    for i in range(9):
+        c.R[i] = float(r.flat[i])
+    for i in range(3):
+        c.t[i] = float(t[i])
+    c.fx = float(camera.params[0])
+    c.fy = float(camera.params[1])
+    c.cam_width = int(camera.width)
+    c.cam_height = int(camera.height)
+    c.res_w, c.res_h = int(result_size[0]), int(result_size[1])
+    c.tile_size = int(tile_size)
+    c.sh_degree = int(degrees)
+    return c
+
+
+class GaussianSet:
+    """Parameter container with the field names of gaussian.py:31-37 (the live constructor)."""
+
+    def __init__(self, centers, shs, scales, rots, opacities, degrees=3):
+        self.center = centers
+        self.spherical_harmonics = shs    # [N,3,16] (load_model.py:40 layout)
+        self.scaling = scales             # log-scales
+        self.rotation = rots              # (w,x,y,z)
+        self.opacity = opacities
+        self.degrees = degrees
+
+
+def _gaussian_tensors(g, device):
+    N = len(g.center)
+    means = _dev(g.center, torch.float32, device, (N, 3))
+    scales = _dev(g.scaling, torch.float32, device, (N, 3))
+    quats = _dev(g.rotation, torch.float32, device, (N, 4))
+    sh = g.spherical_harmonics
+    shape = tuple(sh.shape)
+    if shape != (N, 3, 16):
+        raise ValueError(f"spherical_harmonics must be [N,3,16] (forward_pass.py:172-204), got {shape}")
+    sh = _dev(sh, torch.float32, device, (N, 3, 16))
+    return N, means, scales, quats, sh
+
+
+# --------------------------------------------------------------------------- forward_pass
+def forward_pass(ctx, queue, program, camera, camera_r, camera_t, gaussians,
+                 result_size=[979, 546], tile_size=16, training=True):
+    """forward_pass.py:25-136.  Returns the 13-tuple (training) or 6-tuple of the reference:
+    centers, depths, colors, conics, [clamped,] tiles_touched, radii[, Ws, Ms, Ts, cov2d, cov3d,
+    dirs]."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    dev = c.device
+    numpy_mode = not _is_t(gaussians.center)
+    N, means, scales, quats, sh = _gaussian_tensors(gaussians, dev)
+    cam = make_camera(camera, camera_r, camera_t, result_size, tile_size, gaussians.degrees)
+    f32, i32 = torch.float32, torch.int32
+    centers = torch.empty((N, 2), dtype=f32, device=dev)
+    depths = torch.empty((N,), dtype=i32, device=dev)
+    colors = torch.empty((N, 3), dtype=f32, device=dev)
+    conics = torch.empty((N, 3), dtype=f32, device=dev)
+    clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev)
+    tiles_touched = torch.empty((N, 2, 2), dtype=i32, device=dev)
+    radii = torch.empty((N,), dtype=i32, device=dev)
+    extras = [None] * 6
+    if training:
+        extras = [torch.empty((N,) + s, dtype=f32, device=dev)
+                  for s in ((6,), (3, 3), (3,), (3,), (6,), (3,))]
+    check(c.lib.gs_preprocess(c.handle, N, _ptr(means), _ptr(scales), _ptr(quats), _ptr(sh),
+                              ctypes.byref(cam), _ptr(centers), _ptr(depths), _ptr(colors), _ptr(conics),
+                              _ptr(clamped), _ptr(tiles_touched), _ptr(radii), *[_ptr(e) for e in extras]),
+          "gs_preprocess")
+    if numpy_mode:
+        f64 = np.float64
+        out = [_np_out(centers, f64), _np_out(depths, np.int32), _np_out(colors, f64), _np_out(conics, f64),
+               _np_out(clamped, f64), _np_out(tiles_touched, np.int32), _np_out(radii, f64)]
+        out += [_np_out(e, f64) for e in extras] if training else []
+    else:
+        out = [centers, depths, colors, conics, clamped, tiles_touched, radii] + (extras if training else [])
+    if training:
+        return tuple(out)
+    return out[0], out[1], out[2], out[3], out[5], out[6]
+
+
+# --------------------------------------------------------------------------- binning
+class TileBinning:
+    """What match_gaus_to_tiles returns in place of the reference's dense u64
+    key_mapper[tiles_x, tiles_y, N] (rasterization.py:8): sorted (tile<<32|depth) keys, gaussian
+    ids and per-tile [start,end), all device-resident."""
+
+    def __init__(self, keys, vals, ranges, D, result_size, tile_size):
+        self.keys, self.vals, self.ranges, self.D = keys, vals, ranges, int(D)
+        self.result_size = [int(result_size[0]), int(result_size[1])]
+        self.tile_size = int(tile_size)
+        self.tiles_x = math.ceil(self.result_size[0] / self.tile_size)
+        self.tiles_y = math.ceil(self.result_size[1] / self.tile_size)
+
+    def gaus_stack(self, i, j):
+        """The reference's per-tile sorted u64 gaus_stack ((g<<32)+depth, rasterization.py:66-71)."""
+        s, e = (int(v) for v in self.ranges[i * self.tiles_y + j].tolist())
+        k = self.keys[s:e].cpu().numpy().view(np.uint64) & np.uint64(0xFFFFFFFF)
+        v = self.vals[s:e].cpu().numpy().astype(np.uint64)
+        return (v << np.uint64(32)) + k
+
+    def sorted_gaussians(self, i, j):
+        s, e = (int(v) for v in self.ranges[i * self.tiles_y + j].tolist())
+        return self.vals[s:e].cpu().numpy()
+
+    def __getitem__(self, ij):
+        return self.gaus_stack(*ij)
+
+
+def match_gaus_to_tiles(ctx, queue, program, tiles_touched, radiis, depths,
+                        result_size=[979, 546], tile_size=16):
+    """rasterization.py:6-25 (+ the per-tile filter/sort of :66-71).  `radiis` is accepted for
+    signature compatibility; like the reference's kernel (quirk Q11) it does not affect the keys."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    dev = c.device
+    N = len(depths)
+    rect = _dev(tiles_touched, torch.int32, dev, (N, 4))
+    dep = _dev(depths, torch.int32, dev, (N,))
+    W, H, ts = int(result_size[0]), int(result_size[1]), int(tile_size)
+    D = ctypes.c_int64(0)
+    check(c.lib.gs_bin_count(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts, ctypes.byref(D)), "gs_bin_count")
+    tiles = math.ceil(W / ts) * math.ceil(H / ts)
+    keys = torch.empty((max(D.value, 1),), dtype=torch.int64, device=dev)
+    vals = torch.empty((max(D.value, 1),), dtype=torch.int32, device=dev)
+    ranges = torch.empty((tiles, 2), dtype=torch.int32, device=dev)
+    check(c.lib.gs_bin_fill(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts, D.value, _ptr(keys), _ptr(vals),
+                            _ptr(ranges)), "gs_bin_fill")
+    return TileBinning(keys[:D.value], vals[:D.value], ranges, D.value, [W, H], ts)
+
+
+def _binning_from_lists(mapped_keys, result_size, tile_size, device):
+    """Accept the dict format the reference's c_rasterize/rasterize expect
+    (mapped_keys[i][j] = {depth: gaussian}, rasterization.py:132,167)."""
+    W, H = int(result_size[0]), int(result_size[1])
+    tx_n, ty_n = math.ceil(W / tile_size), math.ceil(H / tile_size)
+    vals, ranges = [], np.zeros((tx_n * ty_n, 2), dtype=np.int32)
+    pos = 0
+    for i in range(tx_n):
+        for j in range(ty_n):
+            items = sorted(mapped_keys[i][j].items())
+            if items:
+                ranges[i * ty_n + j] = (pos, pos + len(items))
+                vals.extend(int(g) for _, g in items)
+                pos += len(items)
+    v = torch.tensor(vals if vals else [0], dtype=torch.int32, device=device)
+    return TileBinning(None, v[:pos], torch.from_numpy(ranges).to(device), pos, [W, H], tile_size)
+
+
+def _as_binning(mapped_keys, result_size, tile_size, device):
+    if isinstance(mapped_keys, TileBinning):
+        if mapped_keys.result_size != [int(result_size[0]), int(result_size[1])] or \
+                mapped_keys.tile_size != int(tile_size):
+            raise ValueError("mapped_keys was built for a different result_size/tile_size")
+        return mapped_keys
+    return _binning_from_lists(mapped_keys, result_size, tile_size, device)
+
+
+# --------------------------------------------------------------------------- blend
+def _bg3(background_color):
+    b = background_color.detach().cpu().numpy() if _is_t(background_color) else np.asarray(background_color)
+    b = b.astype(np.float64).reshape(3)
+    return (ctypes.c_float * 3)(float(b[0]), float(b[1]), float(b[2]))
+
+
+def blend_forward(c, centers, colors, opacities, conics, binning, bg, pixel_offset):
+    """Device tensors in, (image[W,H,3], n_contrib[W,H], t_final[W,H]) out."""
+    dev = c.device
+    W, H = binning.result_size
+    N = centers.shape[0]
+    image = torch.empty((W, H, 3), dtype=torch.float32, device=dev)
+    n_contrib = torch.empty((W, H), dtype=torch.int32, device=dev)
+    t_final = torch.empty((W, H), dtype=torch.float32, device=dev)
+    check(c.lib.gs_blend_forward(c.handle, N, _ptr(centers), _ptr(colors), _ptr(opacities), _ptr(conics),
+                                 _ptr(binning.vals), _ptr(binning.ranges), binning.D, ctypes.byref(bg), W, H,
+                                 binning.tile_size, float(pixel_offset), _ptr(image), _ptr(n_contrib),
+                                 _ptr(t_final)), "gs_blend_forward")
+    return image, n_contrib, t_final
+
+
+def blend_backward(c, centers, colors, opacities, conics, binning, bg, pixel_offset, n_contrib, t_final,
+                   dL_dimage):
+    dev = c.device
+    W, H = binning.result_size
+    N = centers.shape[0]
+    f32 = torch.float32
+    d_centers = torch.empty((N, 2), dtype=f32, device=dev)
+    d_conics = torch.empty((N, 3), dtype=f32, device=dev)
+    d_opac = torch.empty((N,), dtype=f32, device=dev)
+    d_colors = torch.empty((N, 3), dtype=f32, device=dev)
+    check(c.lib.gs_blend_backward(c.handle, N, _ptr(centers), _ptr(colors), _ptr(opacities), _ptr(conics),
+                                  _ptr(binning.vals), _ptr(binning.ranges), binning.D, ctypes.byref(bg), W, H,
+                                  binning.tile_size, float(pixel_offset), _ptr(n_contrib), _ptr(t_final),
+                                  _ptr(dL_dimage), _ptr(d_centers), _ptr(d_conics), _ptr(d_opac),
+                                  _ptr(d_colors)), "gs_blend_backward")
+    return d_centers, d_conics, d_opac, d_colors
+
+
+def _blend_inputs(c, centers, colors, opacities, conics):
+    dev = c.device
+    N = len(centers)
+    return (N, _dev(centers, torch.float32, dev, (N, 2)), _dev(colors, torch.float32, dev, (N, 3)),
+            _dev(opacities, torch.float32, dev, (N,)), _dev(conics, torch.float32, dev, (N, 3)))
+
+
+def gpu_rasterize(ctx, queue, program, centers, colors, opacities, conics, mapped_keys,
+                  training=True, result_size=[979, 546], tile_size=16, background_color=np.zeros(3),
+                  *, dL_dimage=None, pixel_offset=0.5, return_state=False):
+    """rasterization.py:27-107.  Returns image[W,H,3], or (image, d_colors, d_centers, d_conics,
+    d_opacity) when training.  d_centers is scaled by (.5*W, .5*H) as the reference's kernel does
+    (setup_gpu.py:157-158).  dL_dimage=None reproduces the reference, which uses the rendered
+    image itself as dL/dpixel (setup_gpu.py:112-114,139-140); pass the real loss gradient
+    [W,H,3] to train.  pixel_offset=+0.5 is rasterize.c:103-104."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    numpy_mode = not _is_t(centers)
+    N, cen, col, opa, con = _blend_inputs(c, centers, colors, opacities, conics)
+    binning = _as_binning(mapped_keys, result_size, tile_size, c.device)
+    bg = _bg3(background_color)
+    image, n_contrib, t_final = blend_forward(c, cen, col, opa, con, binning, bg, pixel_offset)
+    conv = (lambda t: _np_out(t, np.float64)) if numpy_mode else (lambda t: t)
+    if not training:
+        return (conv(image), n_contrib, t_final) if return_state else conv(image)
+    W, H = binning.result_size
+    dl = image if dL_dimage is None else _dev(dL_dimage, torch.float32, c.device, (W, H, 3))
+    d_centers, d_conics, d_opac, d_colors = blend_backward(c, cen, col, opa, con, binning, bg, pixel_offset,
+                                                           n_contrib, t_final, dl)
+    d_centers = d_centers * torch.tensor([.5 * W, .5 * H], dtype=torch.float32, device=c.device)
+    out = (conv(image), conv(d_colors), conv(d_centers), conv(d_conics), conv(d_opac))
+    return out + (n_contrib, t_final) if return_state else out
+
+
+def rasterize(centers, colors, opacities, conics, mapped_keys, training=True, result_size=[979, 546],
+              tile_size=16, background_color=np.zeros(3), *, ctx=None):
+    """rasterization.py:155-215 (pixel centre c - (x + .5), i.e. pixel_offset=-0.5); returns
+    image[W,H,3]."""
+    return gpu_rasterize(ctx, None, None, centers, colors, opacities, conics, mapped_keys, training=False,
+                         result_size=result_size, tile_size=tile_size, background_color=background_color,
+                         pixel_offset=-0.5)
+
+
+def c_rasterize(centers, colors, opacities, conics, mapped_keys, training=True, result_size=[979, 546],
+                tile_size=16, background_color=np.zeros(3, dtype=np.float64)):
+    """rasterization.py:109-153: per-tile calls of the native symbol rasterize_tile through ctypes,
+    exactly as the reference binds ./shared.so (host float64 arrays, pixel offset +0.5)."""
+    if int(tile_size) != TILE:
+        raise ValueError("rasterize_tile is compiled for TILE_SIZE 16 (rasterize.c:5)")
+    lib = _lib.load()
+    W, H = int(result_size[0]), int(result_size[1])
+    cen = np.ascontiguousarray(centers, dtype=np.float64)
+    col = np.ascontiguousarray(colors, dtype=np.float64)
+    opa = np.ascontiguousarray(np.asarray(opacities, dtype=np.float64).reshape(-1))
+    con = np.ascontiguousarray(conics, dtype=np.float64)
+    bg = np.ascontiguousarray(background_color, dtype=np.float64)
+    image = np.empty([W, H, 3])
+    last_contributors = np.empty([W, H], dtype=np.int32)
+    chunk = np.zeros([TILE, TILE, 3])
+    lc = np.zeros([TILE, TILE], dtype=np.int32)
+    for i in range(math.ceil(W / TILE)):
+        for j in range(math.ceil(H / TILE)):
+            if isinstance(mapped_keys, TileBinning):
+                stack = np.ascontiguousarray(mapped_keys.sorted_gaussians(i, j), dtype=np.int32)
+            else:
+                items = sorted(mapped_keys[i][j].items())
+                stack = np.asarray([g for _, g in items], dtype=np.int32)
+            sp = stack if len(stack) else np.zeros(1, dtype=np.int32)
+            p = lambda a: ctypes.c_void_p(a.ctypes.data)
+            check(lib.rasterize_tile(p(chunk), p(lc), p(cen), p(col), p(opa), p(con), p(sp), p(bg),
+                                     len(stack), int(bool(training)), i, j, W, H), "rasterize_tile")
+            lx, ly = min((i + 1) * TILE, W), min((j + 1) * TILE, H)
+            cx, cy = lx - i * TILE, ly - j * TILE
+            image[i * TILE:lx, j * TILE:ly] = chunk[:cx, :cy]
+            last_contributors[i * TILE:lx, j * TILE:ly] = lc[:cx, :cy]
+    c_rasterize.last_contributors = last_contributors
+    return image
+
+
+# --------------------------------------------------------------------------- backward_pass
+def backward_params(c, means, scales, quats, sh, cam, radii, clamped, d_centers_px, d_conics, d_colors,
+                    out=None, accumulate=False):
+    """Device tensors in; returns (dL_dmeans, dL_dlog_scales, dL_dquats, dL_dsh[N,3,16])."""
+    dev = c.device
+    N = means.shape[0]
+    f32 = torch.float32
+    if out is None:
+        out = (torch.empty((N, 3), dtype=f32, device=dev), torch.empty((N, 3), dtype=f32, device=dev),
+               torch.empty((N, 4), dtype=f32, device=dev), torch.empty((N, 3, 16), dtype=f32, device=dev))
+    check(c.lib.gs_backward_params(c.handle, N, _ptr(means), _ptr(scales), _ptr(quats), _ptr(sh),
+                                   ctypes.byref(cam), _ptr(radii), _ptr(clamped), _ptr(d_centers_px),
+                                   _ptr(d_conics), _ptr(d_colors), int(bool(accumulate)), _ptr(out[0]),
+                                   _ptr(out[1]), _ptr(out[2]), _ptr(out[3])), "gs_backward_params")
+    return out
+
+
+def backward_pass(ctx, queue, program, camera, camera_r, camera_t, gaussians,
+                  radii, covs_2d, covs_3d, ws, ms, ts, dirs, clampeds,
+                  d_colors, d_2d_centers, d_conics, *, result_size=[979, 546], tile_size=16):
+    """backward_pass.py:19-68 -> (d_colors, d_centers, d_shs, d_scales, d_rots).
+
+    d_colors: the incoming colour gradient masked by the clamp flags (the intent of
+    setup_gpu.py:279-281); d_centers[N,3]: dL/d(world mean); d_shs[N,16,3] (the reference's layout,
+    backward_pass.py:73); d_scales[N,3]: dL/d(log-scale parameter) (defect B13: the reference
+    mixes activated and log scales); d_rots[N,4]: dL/d(un-normalised quaternion).
+    d_2d_centers uses gpu_rasterize's convention (scaled by .5*W, .5*H).  covs_2d, covs_3d, ws,
+    ms, ts and dirs are accepted for signature compatibility; the kernel recomputes them."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    dev = c.device
+    numpy_mode = not _is_t(gaussians.center)
+    N, means, scales, quats, sh = _gaussian_tensors(gaussians, dev)
+    for name, arr, tail in (("covs_2d", covs_2d, 3), ("covs_3d", covs_3d, 6), ("ws", ws, 6), ("ts", ts, 3),
+                            ("dirs", dirs, 3)):
+        if arr is not None and (len(arr) != N or int(np.prod(arr.shape[1:])) != tail):
+            raise ValueError(f"{name} must be [N,{tail}]")
+    if ms is not None and (len(ms) != N or int(np.prod(ms.shape[1:])) != 9):
+        raise ValueError("ms must be [N,3,3]")
+    cam = make_camera(camera, camera_r, camera_t, result_size, tile_size, gaussians.degrees)
+    rad = _dev(radii, torch.int32, dev, (N,))
+    cl = _dev(clampeds, torch.uint8, dev, (N, 3))
+    W, H = int(result_size[0]), int(result_size[1])
+    d2 = _dev(d_2d_centers, torch.float32, dev, (N, 2)) / torch.tensor([.5 * W, .5 * H], dtype=torch.float32,
+                                                                       device=dev)
+    dcon = _dev(d_conics, torch.float32, dev, (N, 3))
+    dcol = _dev(d_colors, torch.float32, dev, (N, 3))
+    g_means, g_scales, g_quats, g_sh = backward_params(c, means, scales, quats, sh, cam, rad, cl,
+                                                       d2.contiguous(), dcon, dcol)
+    d_colors_out = dcol * (cl == 0).to(torch.float32)
+    d_shs = g_sh.permute(0, 2, 1).contiguous()     # [N,16,3]
+    outs = (d_colors_out, g_means, d_shs, g_scales, g_quats)
+    if numpy_mode:
+        return tuple(_np_out(o, np.float64) for o in outs)
+    return outs

@@ -1,0 +1,399 @@
+// K6 blend forward / K7 blend backward, one workgroup per 16x16 tile.
+//
+// K6 replaces the forward part of kernel rasterize (setup_gpu.py:46-100; one launch per tile in
+// the reference, rasterization.py:62-98), rasterize_tile/thread_rasterize (rasterize.c:27-132)
+// and the pure-Python rasterize (rasterization.py:155-215).
+// K7 replaces the backward part of kernel rasterize (setup_gpu.py:105-165) by intent (defects
+// B4-B8 are not reproduced): reverse traversal from each pixel's last contributor.
+//
+// Mapping (wave64 first): a workgroup has 256/PPT threads and every thread owns PPT vertically
+// adjacent pixels of one column, so the per-gaussian terms that depend on x only are computed once
+// per thread.  With PPT=4 a tile is ONE wavefront: the "all pixels done" early exit is a single
+// ballot, no cross-wave reduction is needed in the backward pass, and the gaussian parameters are
+// staged through LDS in wavefront-sized (64) batches and read back as broadcasts.
+// Both kernels are bound by the FP32 vector ALU (exp + ~20 FMA-class ops per pixel-gaussian
+// pair), not by HBM or MFMA: no stage is a dense contraction.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr float ALPHA_MAX = 0.99f;          // rasterize.c:112
+constexpr float ALPHA_MIN = 1.0f / 255.0f;  // rasterize.c:114
+constexpr float T_MIN = 0.0001f;            // rasterize.c:118
+
+struct BlendArgs {
+    const float2 *centers;
+    const float *colors;
+    const float *opacities;
+    const float *conics;
+    const int32_t *vals;
+    const int2 *ranges;
+    float bg[3];
+    int W, H, tiles_y;
+    float pixel_offset;
+};
+
+// Shared by K6 and K7 so both take bit-identical skip decisions (rasterize.c:103-115):
+// power = -.5*(A dx^2 + C dy^2) - B dx dy, written as pa + dy*(pb + pc*dy) with
+// pa = -.5*A*dx*dx, pb = -B*dx, pc = -.5*C.
+__device__ __forceinline__ float eval_power(float pa, float pb, float pc, float dy) {
+    return __builtin_fmaf(dy, __builtin_fmaf(pc, dy, pb), pa);
+}
+
+template <int PPT>
+struct Geo {
+    static constexpr int NT = 256 / PPT;     // threads per tile = batch size
+    static constexpr int YQ = TILE / PPT;    // threads per pixel column
+};
+
+// ------------------------------------------------------------------------------------------ K6
+template <int PPT>
+__global__ __launch_bounds__(256 / PPT) void blend_fwd_kernel(BlendArgs a, float *__restrict__ image,
+                                                              int32_t *__restrict__ n_contrib,
+                                                              float *__restrict__ t_final) {
+    constexpr int NT = Geo<PPT>::NT, YQ = Geo<PPT>::YQ;
+    __shared__ float2 s_xy[NT];
+    __shared__ float4 s_co[NT];    // conic A, B, C, opacity
+    __shared__ float4 s_rgb[NT];
+
+    const int tile = blockIdx.x;
+    const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
+    const int t = threadIdx.x;
+    const int lx = t / YQ, yq = t % YQ;
+    const int px = tx * TILE + lx, py0 = ty * TILE + yq * PPT;
+    const float fx = (float)px - a.pixel_offset;   // dist_x = c.x - x + off
+    const int2 rg = a.ranges[tile];
+    const int len = rg.y - rg.x;
+
+    float fy[PPT], T[PPT], C[PPT][3];
+    int last[PPT];
+    bool done[PPT], broke[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        fy[k] = (float)(py0 + k) - a.pixel_offset;
+        T[k] = 1.0f;
+        C[k][0] = C[k][1] = C[k][2] = 0.0f;
+        last[k] = len;
+        broke[k] = false;
+        done[k] = !(px < a.W && py0 + k < a.H);
+    }
+
+    for (int base = 0; base < len; base += NT) {
+        bool all_done = true;
+#pragma unroll
+        for (int k = 0; k < PPT; k++) all_done = all_done && done[k];
+        if (__syncthreads_and(all_done)) break;   // also fences the previous batch's LDS reads
+        const int n = min(NT, len - base);
+        if (t < n) {
+            const int g = a.vals[rg.x + base + t];
+            s_xy[t] = a.centers[g];
+            s_co[t] = make_float4(a.conics[3 * g], a.conics[3 * g + 1], a.conics[3 * g + 2], a.opacities[g]);
+            s_rgb[t] = make_float4(a.colors[3 * g], a.colors[3 * g + 1], a.colors[3 * g + 2], 0.0f);
+        }
+        __syncthreads();
+        for (int j = 0; j < n; j++) {
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float dx = xy.x - fx;
+            const float pa = -0.5f * co.x * dx * dx, pb = -co.y * dx, pc = -0.5f * co.z;
+            const float4 rgb = s_rgb[j];
+#pragma unroll
+            for (int k = 0; k < PPT; k++) {
+                if (done[k]) continue;
+                const float dy = xy.y - fy[k];
+                const float power = eval_power(pa, pb, pc, dy);
+                if (power > 0.0f) continue;
+                const float alpha = fminf(ALPHA_MAX, co.w * __expf(power));
+                if (alpha < ALPHA_MIN) continue;
+                const float test_T = T[k] * (1.0f - alpha);
+                if (test_T < T_MIN) {
+                    done[k] = true;
+                    broke[k] = true;
+                    last[k] = base + j + 1;    // counts the entry that triggers the break
+                    continue;
+                }
+                const float w = alpha * T[k];
+                C[k][0] = __builtin_fmaf(rgb.x, w, C[k][0]);
+                C[k][1] = __builtin_fmaf(rgb.y, w, C[k][1]);
+                C[k][2] = __builtin_fmaf(rgb.z, w, C[k][2]);
+                T[k] = test_T;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int py = py0 + k;
+        if (px < a.W && py < a.H) {
+            const size_t p = (size_t)px * a.H + py;
+            image[3 * p] = __builtin_fmaf(a.bg[0], T[k], C[k][0]);
+            image[3 * p + 1] = __builtin_fmaf(a.bg[1], T[k], C[k][1]);
+            image[3 * p + 2] = __builtin_fmaf(a.bg[2], T[k], C[k][2]);
+            n_contrib[p] = last[k] | (broke[k] ? (int32_t)0x80000000 : 0);
+            t_final[p] = T[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K7
+// wave64 sum to lane 63 with DPP: 4 row_shr steps (inclusive scan inside each 16-lane row), then
+// row_bcast:15 and row_bcast:31 carry the row totals upwards.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v += dpp_term<0x111, 0xF>(v);   // row_shr:1
+    v += dpp_term<0x112, 0xF>(v);   // row_shr:2
+    v += dpp_term<0x114, 0xF>(v);   // row_shr:4
+    v += dpp_term<0x118, 0xF>(v);   // row_shr:8
+    v += dpp_term<0x142, 0xA>(v);   // row_bcast:15 -> rows 1,3
+    v += dpp_term<0x143, 0xC>(v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+constexpr int GRAD_ROW = 16;   // floats per gaussian in the 64-byte gradient rows
+// row layout: 0,1 d/dcenter  2,3,4 d/dconic  5 d/dopacity  6,7,8 d/dcolor
+
+template <int PPT>
+__global__ __launch_bounds__(256 / PPT) void blend_bwd_kernel(BlendArgs a, const int32_t *__restrict__ n_contrib,
+                                                              const float *__restrict__ t_final,
+                                                              const float *__restrict__ dL_dimage,
+                                                              float *__restrict__ grad_rows) {
+    constexpr int NT = Geo<PPT>::NT, YQ = Geo<PPT>::YQ;
+    __shared__ float2 s_xy[NT];
+    __shared__ float4 s_co[NT];
+    __shared__ float4 s_rgb[NT];
+    __shared__ int s_g[NT];
+    __shared__ float s_grad[NT][9];
+    __shared__ int s_max_end;
+
+    const int tile = blockIdx.x;
+    const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int lx = t / YQ, yq = t % YQ;
+    const int px = tx * TILE + lx, py0 = ty * TILE + yq * PPT;
+    const float fx = (float)px - a.pixel_offset;
+    const int2 rg = a.ranges[tile];
+
+    float fy[PPT], T[PPT], Tf_bg[PPT], dLp[PPT][3], acc_rec[PPT][3], last_col[PPT][3], last_alpha[PPT];
+    int end_k[PPT];
+    int my_max = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int py = py0 + k;
+        fy[k] = (float)py - a.pixel_offset;
+        end_k[k] = 0;
+        T[k] = 1.0f;
+        Tf_bg[k] = 0.0f;
+        last_alpha[k] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) dLp[k][c] = acc_rec[k][c] = last_col[k][c] = 0.0f;
+        if (px < a.W && py < a.H) {
+            const size_t p = (size_t)px * a.H + py;
+            const int32_t nc = n_contrib[p];
+            const int cnt = nc & 0x7fffffff;
+            end_k[k] = (nc < 0) ? cnt - 1 : cnt;   // the breaking entry was not blended
+            T[k] = t_final[p];
+#pragma unroll
+            for (int c = 0; c < 3; c++) dLp[k][c] = dL_dimage[3 * p + c];
+            // background term of dL/dalpha: -T_final/(1-alpha) * (bg . dL/dpixel)
+            Tf_bg[k] = T[k] * (a.bg[0] * dLp[k][0] + a.bg[1] * dLp[k][1] + a.bg[2] * dLp[k][2]);
+        }
+        my_max = max(my_max, end_k[k]);
+    }
+    if (t == 0) s_max_end = 0;
+    __syncthreads();
+    atomicMax(&s_max_end, my_max);
+    __syncthreads();
+    const int max_end = s_max_end;
+
+    const int nbatch = (max_end + NT - 1) / NT;
+    for (int b = nbatch - 1; b >= 0; b--) {
+        const int base = b * NT;
+        const int n = min(NT, max_end - base);
+        __syncthreads();   // previous batch fully flushed
+        if (t < n) {
+            const int g = a.vals[rg.x + base + t];
+            s_g[t] = g;
+            s_xy[t] = a.centers[g];
+            s_co[t] = make_float4(a.conics[3 * g], a.conics[3 * g + 1], a.conics[3 * g + 2], a.opacities[g]);
+            s_rgb[t] = make_float4(a.colors[3 * g], a.colors[3 * g + 1], a.colors[3 * g + 2], 0.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < 9; c++) s_grad[t][c] = 0.0f;
+        __syncthreads();
+
+        for (int j = n - 1; j >= 0; j--) {
+            const int idx = base + j;
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float4 rgb = s_rgb[j];
+            const float dx = xy.x - fx;
+            const float pa = -0.5f * co.x * dx * dx, pb = -co.y * dx, pc = -0.5f * co.z;
+            float g_cx = 0.f, g_cy = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < PPT; k++) {
+                if (idx >= end_k[k]) continue;
+                const float dy = xy.y - fy[k];
+                const float power = eval_power(pa, pb, pc, dy);
+                if (power > 0.0f) continue;
+                const float G = __expf(power);
+                const float alpha_raw = co.w * G;
+                const float alpha = fminf(ALPHA_MAX, alpha_raw);
+                if (alpha < ALPHA_MIN) continue;
+                any = true;
+                const float inv_1ma = 1.0f / (1.0f - alpha);
+                T[k] = T[k] * inv_1ma;              // transmittance in front of this gaussian
+                const float w = alpha * T[k];
+                g_r = __builtin_fmaf(w, dLp[k][0], g_r);
+                g_g = __builtin_fmaf(w, dLp[k][1], g_g);
+                g_b = __builtin_fmaf(w, dLp[k][2], g_b);
+                // colour accumulated behind this gaussian, per unit transmittance
+                acc_rec[k][0] = __builtin_fmaf(last_alpha[k], last_col[k][0] - acc_rec[k][0], acc_rec[k][0]);
+                acc_rec[k][1] = __builtin_fmaf(last_alpha[k], last_col[k][1] - acc_rec[k][1], acc_rec[k][1]);
+                acc_rec[k][2] = __builtin_fmaf(last_alpha[k], last_col[k][2] - acc_rec[k][2], acc_rec[k][2]);
+                last_col[k][0] = rgb.x; last_col[k][1] = rgb.y; last_col[k][2] = rgb.z;
+                last_alpha[k] = alpha;
+                float dL_dalpha = (rgb.x - acc_rec[k][0]) * dLp[k][0] + (rgb.y - acc_rec[k][1]) * dLp[k][1] +
+                                  (rgb.z - acc_rec[k][2]) * dLp[k][2];
+                dL_dalpha = dL_dalpha * T[k] - Tf_bg[k] * inv_1ma;
+                if (alpha_raw <= ALPHA_MAX) {        // min(.99, .) passes no gradient when active
+                    const float q = co.w * dL_dalpha * G;     // dL/dG * G
+                    g_o = __builtin_fmaf(G, dL_dalpha, g_o);
+                    g_cx = __builtin_fmaf(q, -(co.x * dx + co.y * dy), g_cx);
+                    g_cy = __builtin_fmaf(q, -(co.z * dy + co.y * dx), g_cy);
+                    g_A = __builtin_fmaf(-0.5f * dx * dx, q, g_A);
+                    g_B = __builtin_fmaf(-dx * dy, q, g_B);
+                    g_C = __builtin_fmaf(-0.5f * dy * dy, q, g_C);
+                }
+            }
+            if (__any(any)) {   // wave-uniform: skip the reduction when no lane contributed
+                g_cx = wave_sum_to_lane63(g_cx); g_cy = wave_sum_to_lane63(g_cy);
+                g_A = wave_sum_to_lane63(g_A); g_B = wave_sum_to_lane63(g_B); g_C = wave_sum_to_lane63(g_C);
+                g_o = wave_sum_to_lane63(g_o);
+                g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+                if (lane == 63) {
+                    if (NT == 64) {   // single wave per tile: plain LDS stores
+                        s_grad[j][0] = g_cx; s_grad[j][1] = g_cy; s_grad[j][2] = g_A; s_grad[j][3] = g_B;
+                        s_grad[j][4] = g_C; s_grad[j][5] = g_o; s_grad[j][6] = g_r; s_grad[j][7] = g_g;
+                        s_grad[j][8] = g_b;
+                    } else {
+                        atomicAdd(&s_grad[j][0], g_cx); atomicAdd(&s_grad[j][1], g_cy);
+                        atomicAdd(&s_grad[j][2], g_A); atomicAdd(&s_grad[j][3], g_B);
+                        atomicAdd(&s_grad[j][4], g_C); atomicAdd(&s_grad[j][5], g_o);
+                        atomicAdd(&s_grad[j][6], g_r); atomicAdd(&s_grad[j][7], g_g);
+                        atomicAdd(&s_grad[j][8], g_b);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // flush: one 64-byte row per gaussian, 4 rows per wave-instruction, lanes 0..8 of each
+        // 16-lane group active -> one memory-side atomic request per (tile, gaussian)
+        const int comp = t & 15;
+        for (int e = t >> 4; e < n; e += NT / 16) {
+            if (comp < 9) {
+                const float v = s_grad[e][comp];
+                if (v != 0.0f) atomicAdd(&grad_rows[(size_t)s_g[e] * GRAD_ROW + comp], v);
+            }
+        }
+    }
+}
+
+// grad rows -> the reference's four arrays (gpu_rasterize return tuple, rasterization.py:105)
+__global__ __launch_bounds__(256) void unpack_rows_kernel(int N, const float *__restrict__ rows,
+                                                          float *__restrict__ d_centers, float *__restrict__ d_conics,
+                                                          float *__restrict__ d_opac, float *__restrict__ d_colors) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float4 *r = reinterpret_cast<const float4 *>(rows + (size_t)i * GRAD_ROW);
+    const float4 r0 = r[0], r1 = r[1];
+    const float r8 = rows[(size_t)i * GRAD_ROW + 8];
+    d_centers[2 * i] = r0.x; d_centers[2 * i + 1] = r0.y;
+    d_conics[3 * i] = r0.z; d_conics[3 * i + 1] = r0.w; d_conics[3 * i + 2] = r1.x;
+    d_opac[i] = r1.y;
+    d_colors[3 * i] = r1.z; d_colors[3 * i + 1] = r1.w; d_colors[3 * i + 2] = r8;
+}
+
+int fill_args(BlendArgs &a, gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+              const float *opacities, const float *conics, const int32_t *vals, const int32_t *ranges,
+              int64_t D, const float *bg, int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset) {
+    GS_REQUIRE(ctx, "gs_blend: ctx is NULL");
+    GS_REQUIRE(tile_size == TILE, "gs_blend: tile_size %d unsupported (only 16, rasterize.c:5)", tile_size);
+    GS_REQUIRE(res_w > 0 && res_h > 0, "gs_blend: invalid frame %dx%d", res_w, res_h);
+    GS_REQUIRE(N >= 0 && D >= 0, "gs_blend: negative N or D");
+    GS_REQUIRE(ranges && bg, "gs_blend: ranges/background is NULL");
+    GS_REQUIRE(D == 0 || (centers && colors && opacities && conics && vals), "gs_blend: NULL array argument");
+    GS_REQUIRE(((uintptr_t)centers & 7) == 0 && ((uintptr_t)ranges & 7) == 0,
+               "gs_blend: centers and ranges must be 8-byte aligned");
+    a.centers = reinterpret_cast<const float2 *>(centers);
+    a.colors = colors; a.opacities = opacities; a.conics = conics; a.vals = vals;
+    a.ranges = reinterpret_cast<const int2 *>(ranges);
+    a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2];
+    a.W = res_w; a.H = res_h; a.tiles_y = gs_div_up(res_h, TILE);
+    a.pixel_offset = pixel_offset;
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                                const float *opacities, const float *conics, const int32_t *vals,
+                                const int32_t *ranges, int64_t D, const float *background_host3,
+                                int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                                float *image, int32_t *n_contrib, float *t_final) {
+    BlendArgs a;
+    int rc = fill_args(a, ctx, N, centers, colors, opacities, conics, vals, ranges, D, background_host3,
+                       res_w, res_h, tile_size, pixel_offset);
+    if (rc) return rc;
+    GS_REQUIRE(image && n_contrib && t_final, "gs_blend_forward: NULL output");
+    GS_HIP(hipSetDevice(ctx->device));
+    const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
+    switch (ctx->ppt) {
+        case 1: hipLaunchKernelGGL(blend_fwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, image, n_contrib, t_final); break;
+        case 2: hipLaunchKernelGGL(blend_fwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, image, n_contrib, t_final); break;
+        default: hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(tiles), dim3(64), 0, ctx->stream, a, image, n_contrib, t_final); break;
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_blend_backward(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                                 const float *opacities, const float *conics, const int32_t *vals,
+                                 const int32_t *ranges, int64_t D, const float *background_host3,
+                                 int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                                 const int32_t *n_contrib, const float *t_final, const float *dL_dimage,
+                                 float *dL_dcenters, float *dL_dconics, float *dL_dopacities,
+                                 float *dL_dcolors) {
+    BlendArgs a;
+    int rc = fill_args(a, ctx, N, centers, colors, opacities, conics, vals, ranges, D, background_host3,
+                       res_w, res_h, tile_size, pixel_offset);
+    if (rc) return rc;
+    GS_REQUIRE(n_contrib && t_final && dL_dimage, "gs_blend_backward: NULL forward state / dL_dimage");
+    GS_REQUIRE(N == 0 || (dL_dcenters && dL_dconics && dL_dopacities && dL_dcolors),
+               "gs_blend_backward: NULL output");
+    if (N == 0) return GS_OK;
+    GS_HIP(hipSetDevice(ctx->device));
+    if ((rc = gs_buf_reserve(ctx, &ctx->grad_rows, (size_t)N * GRAD_ROW * sizeof(float)))) return rc;
+    float *rows = (float *)ctx->grad_rows.p;
+    GS_HIP(hipMemsetAsync(rows, 0, (size_t)N * GRAD_ROW * sizeof(float), ctx->stream));
+    const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
+    if (D > 0) {
+        switch (ctx->ppt) {
+            case 1: hipLaunchKernelGGL(blend_bwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); break;
+            case 2: hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); break;
+            default: hipLaunchKernelGGL(blend_bwd_kernel<4>, dim3(tiles), dim3(64), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); break;
+        }
+        GS_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, rows,
+                       dL_dcenters, dL_dconics, dL_dopacities, dL_dcolors);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}

@@ -1,0 +1,57 @@
+// Internal definitions shared by the translation units of libgsplat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gsplat.h"
+
+#define GS_OK 0
+#define GS_ERR_ARG (-1)
+#define GS_ERR_HIP (-2)
+#define GS_ERR_STATE (-3)
+
+int gs_set_error(int code, const char *fmt, ...);
+
+#define GS_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return gs_set_error(GS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+#define GS_REQUIRE(cond, ...)                                                              \
+    do {                                                                                   \
+        if (!(cond)) return gs_set_error(GS_ERR_ARG, __VA_ARGS__);                         \
+    } while (0)
+
+// grow-only device buffer owned by the ctx (no hipMalloc in steady state)
+struct gs_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct gs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // binning workspace
+    gs_buf offsets;      // u32[N]     exclusive scan of tiles-per-gaussian
+    gs_buf block_sums;   // u32[nblocks]
+    gs_buf total;        // u64[1]     D on device
+    gs_buf keys_tmp;     // u64[D]     unsorted keys
+    gs_buf vals_tmp;     // i32[D]
+    gs_buf sort_tmp;     // radix sort temporary storage
+    // blend workspace
+    gs_buf packed;       // float4[3][N] packed per-gaussian blend attributes
+    gs_buf grad_rows;    // float[N][16] 64-byte gradient rows for blend backward
+    gs_buf tile_scratch; // rasterize_tile shim staging
+    uint64_t *total_host = nullptr;   // pinned
+    // state carried from gs_bin_count to gs_bin_fill
+    int ppt = 4;         // pixels per thread of the blend kernels (1, 2 or 4)
+    int32_t bin_N = -1;
+    int64_t bin_D = -1;
+};
+
+int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);
+
+static inline int gs_div_up(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,255 @@
+// K8 per-gaussian parameter backward: replaces backward_pass (backward_pass.py:19-68),
+// cov_2d_backpass + kernel cov_2d_grads (backward_pass.py:99-133, setup_gpu.py:168-253),
+// sh_backpass + kernel sh_grads/dnormvdv (backward_pass.py:70-97, setup_gpu.py:256-303) and the
+// host d_scales/d_rots loop (backward_pass.py:40-66).
+//
+// The reference's versions are undefined at HEAD (defects B3, B9, B10, B13), so this kernel
+// implements the evident intent: the exact derivative of the LIVE forward path
+// (forward_pass.py:56-127 with quirks Q1-Q5) w.r.t. the stored parameters, pinned by fp64 autograd
+// of the oracle restatement.  One thread per gaussian; HBM-bound (236 B parameters + 36 B incoming
+// gradients in, 236 B out), so the forward intermediates (R, M, Sigma, W rows, cov2d) are
+// recomputed in fp64 from the parameters rather than re-read (132 B of extras in the reference).
+#include "common.h"
+#include "precam.h"
+#include <math.h>
+
+namespace {
+
+__global__ __launch_bounds__(256) void param_bwd_kernel(
+    int N, const float *__restrict__ means, const float *__restrict__ log_scales,
+    const float *__restrict__ quats, const float *__restrict__ sh, PreCam cam,
+    const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
+    const float *__restrict__ dL_dcenters, const float *__restrict__ dL_dconics,
+    const float *__restrict__ dL_dcolors, int accumulate, float *__restrict__ dL_dmeans,
+    float *__restrict__ dL_dlog_scales, float *__restrict__ dL_dquats, float *__restrict__ dL_dsh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+
+    double g_mean[3] = {0, 0, 0}, g_ls[3] = {0, 0, 0}, g_q[4] = {0, 0, 0, 0};
+    float4 *out_sh = reinterpret_cast<float4 *>(dL_dsh + (size_t)i * 48);
+    const bool visible = radii[i] > 0;
+
+    if (visible) {
+        const double x = means[3 * i], y = means[3 * i + 1], z = means[3 * i + 2];
+
+        // ---- 2D centre <- world mean (quirk Q1: proj_mat on world coordinates)
+        {
+            const double dcx = dL_dcenters[2 * i], dcy = dL_dcenters[2 * i + 1];
+            const double mw = 1.0 / (z + .00000001);
+            g_mean[0] += dcx * (.5 * cam.W * cam.p00 * mw);
+            g_mean[1] += dcy * (.5 * cam.H * cam.p11 * mw);
+            g_mean[2] += -dcx * (.5 * cam.W * cam.p00 * x * mw * mw) - dcy * (.5 * cam.H * cam.p11 * y * mw * mw);
+        }
+
+        // ---- recompute R, S', M, Sigma, W rows, cov2d (forward_pass.py:74-86)
+        const double tz = cam.Rt[6] * x + cam.Rt[7] * y + cam.Rt[8] * z + cam.t[2];
+        const double qw = quats[4 * i], qx = quats[4 * i + 1], qy = quats[4 * i + 2], qz = quats[4 * i + 3];
+        const double n2 = qw * qw + qx * qx + qy * qy + qz * qz;
+        const double s = 2.0 / n2;
+        const double Q[9] = {-(qy * qy + qz * qz), qx * qy - qz * qw, qx * qz + qy * qw,
+                             qx * qy + qz * qw, -(qx * qx + qz * qz), qy * qz - qx * qw,
+                             qx * qz - qy * qw, qy * qz + qx * qw, -(qx * qx + qy * qy)};
+        double R[9];
+        for (int k = 0; k < 9; k++) R[k] = s * Q[k];
+        R[0] += 1.0; R[4] += 1.0; R[8] += 1.0;
+        const double sm = cam.scale_mod;
+        const double sc[3] = {exp((double)log_scales[3 * i]), exp((double)log_scales[3 * i + 1]),
+                              exp((double)log_scales[3 * i + 2])};
+        const double S[9] = {sc[0] * sm, sm, sm, sm, sc[1] * sm, sm, sm, sm, sc[2] * sm};
+        double M[9], Sg[9];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++)
+                M[3 * r + c] = R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++)
+                Sg[3 * r + c] = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2];
+        const double j00 = cam.fx / tz, j11 = cam.fy / tz;
+        const double W0[3] = {j00 * cam.Rt[0], j00 * cam.Rt[1], j00 * cam.Rt[2]};
+        const double W1[3] = {j11 * cam.Rt[3], j11 * cam.Rt[4], j11 * cam.Rt[5]};
+        double u0[3], u1[3];
+        for (int r = 0; r < 3; r++) {
+            u0[r] = Sg[3 * r] * W0[0] + Sg[3 * r + 1] * W0[1] + Sg[3 * r + 2] * W0[2];
+            u1[r] = Sg[3 * r] * W1[0] + Sg[3 * r + 1] * W1[1] + Sg[3 * r + 2] * W1[2];
+        }
+        const double a0 = W0[0] * u0[0] + W0[1] * u0[1] + W0[2] * u0[2];
+        const double b = W0[0] * u1[0] + W0[1] * u1[1] + W0[2] * u1[2];
+        const double c0 = W1[0] * u1[0] + W1[1] * u1[1] + W1[2] * u1[2];
+        const double a = a0 + .3, c = c0 + .3;
+        const double det = a * c - b * b;
+
+        // ---- conic (A,B,C) = (c, -b, a)/det  ->  cov2d (a,b,c)
+        const double gA = dL_dconics[3 * i], gB = dL_dconics[3 * i + 1], gC = dL_dconics[3 * i + 2];
+        const double inv2 = 1.0 / (det * det);
+        const double d_a = (-c * c * gA + b * c * gB - b * b * gC) * inv2;
+        const double d_b = (2.0 * b * c * gA - (det + 2.0 * b * b) * gB + 2.0 * a * b * gC) * inv2;
+        const double d_c = (-b * b * gA + a * b * gB - a * a * gC) * inv2;
+
+        // ---- cov2d -> tz (through the 1/tz of both W rows) -> mean
+        {
+            const double d_tz = -2.0 * (d_a * a0 + d_b * b + d_c * c0) / tz;
+            g_mean[0] += d_tz * cam.Rt[6];
+            g_mean[1] += d_tz * cam.Rt[7];
+            g_mean[2] += d_tz * cam.Rt[8];
+        }
+
+        // ---- cov2d -> Sigma (G) -> M: dM = (G + G^T) M
+        double H[9];   // G + G^T
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++) {
+                const double g_rc = d_a * W0[r] * W0[cc] + d_b * W0[r] * W1[cc] + d_c * W1[r] * W1[cc];
+                const double g_cr = d_a * W0[cc] * W0[r] + d_b * W0[cc] * W1[r] + d_c * W1[cc] * W1[r];
+                H[3 * r + cc] = g_rc + g_cr;
+            }
+        double dM[9];
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++)
+                dM[3 * r + cc] = H[3 * r] * M[cc] + H[3 * r + 1] * M[3 + cc] + H[3 * r + 2] * M[6 + cc];
+
+        // ---- M = R S': d(log scale_k) = (R^T dM)_kk * scale_mod * s_k
+        for (int k = 0; k < 3; k++) {
+            const double dS_kk = R[k] * dM[k] + R[3 + k] * dM[3 + k] + R[6 + k] * dM[6 + k];
+            g_ls[k] = dS_kk * sm * sc[k];
+        }
+        // dR = dM S'^T
+        double dR[9];
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++)
+                dR[3 * r + cc] = dM[3 * r] * S[3 * cc] + dM[3 * r + 1] * S[3 * cc + 1] + dM[3 * r + 2] * S[3 * cc + 2];
+        // R = I + (2/n2) Q(q)  (normalise-then-divide-by-squared-norm is scale invariant)
+        {
+            double QD = 0.0;
+            for (int k = 0; k < 9; k++) QD += Q[k] * dR[k];
+            const double D00 = dR[0], D01 = dR[1], D02 = dR[2], D10 = dR[3], D11 = dR[4], D12 = dR[5],
+                         D20 = dR[6], D21 = dR[7], D22 = dR[8];
+            const double pw = -qz * D01 + qy * D02 + qz * D10 - qx * D12 - qy * D20 + qx * D21;
+            const double px = qy * D01 + qz * D02 + qy * D10 - 2 * qx * D11 - qw * D12 + qz * D20 + qw * D21 - 2 * qx * D22;
+            const double py = -2 * qy * D00 + qx * D01 + qw * D02 + qx * D10 + qz * D12 - qw * D20 + qz * D21 - 2 * qy * D22;
+            const double pz = -2 * qz * D00 - qw * D01 + qx * D02 + qw * D10 - 2 * qz * D11 + qy * D12 + qx * D20 + qy * D21;
+            const double k2 = 2.0 * s * QD / n2;   // (4 QD / n2^2)
+            g_q[0] = s * pw - k2 * qw;
+            g_q[1] = s * px - k2 * qx;
+            g_q[2] = s * py - k2 * qy;
+            g_q[3] = s * pz - k2 * qz;
+        }
+
+        // ---- colour -> SH coefficients and view direction -> mean (py_compute_color)
+        double vx = x - cam.cam_pos[0], vy = y - cam.cam_pos[1], vz = z - cam.cam_pos[2];
+        const double vn = sqrt(vx * vx + vy * vy + vz * vz);
+        const double dx = vx / vn, dy = vy / vn, dz = vz / vn;
+        double basis[16], bx[16], by[16], bz[16];
+        for (int k = 0; k < 16; k++) basis[k] = bx[k] = by[k] = bz[k] = 0.0;
+        basis[0] = SH_C0;
+        if (cam.degree > 0) {
+            basis[1] = -dy * SH_C1; by[1] = -SH_C1;
+            basis[2] = dz * SH_C1;  bz[2] = SH_C1;
+            basis[3] = -dx * SH_C1; bx[3] = -SH_C1;
+            if (cam.degree > 1) {
+                const double xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+                basis[4] = SH_C2_0 * xy; bx[4] = SH_C2_0 * dy; by[4] = SH_C2_0 * dx;
+                basis[5] = SH_C2_1 * yz; by[5] = SH_C2_1 * dz; bz[5] = SH_C2_1 * dy;
+                basis[6] = SH_C2_2 * (2.0 * zz - xx - yy);
+                bx[6] = -2.0 * SH_C2_2 * dx; by[6] = -2.0 * SH_C2_2 * dy; bz[6] = 4.0 * SH_C2_2 * dz;
+                basis[7] = SH_C2_3 * xz; bx[7] = SH_C2_3 * dz; bz[7] = SH_C2_3 * dx;
+                basis[8] = SH_C2_4 * (xx - yy); bx[8] = 2.0 * SH_C2_4 * dx; by[8] = -2.0 * SH_C2_4 * dy;
+                if (cam.degree > 2) {
+                    basis[9] = SH_C3_0 * dy * (3.0 * xx - yy);
+                    bx[9] = SH_C3_0 * 6.0 * xy; by[9] = SH_C3_0 * (3.0 * xx - 3.0 * yy);
+                    basis[10] = SH_C3_1 * xy * dz;
+                    bx[10] = SH_C3_1 * yz; by[10] = SH_C3_1 * xz; bz[10] = SH_C3_1 * xy;
+                    basis[11] = SH_C3_2 * dy * (4.0 * zz - xx - yy);
+                    bx[11] = SH_C3_2 * (-2.0 * xy); by[11] = SH_C3_2 * (4.0 * zz - xx - 3.0 * yy); bz[11] = SH_C3_2 * 8.0 * yz;
+                    basis[12] = SH_C3_3 * dz * (2.0 * zz - 3.0 * xx - 3.0 * yy);
+                    bx[12] = SH_C3_3 * (-6.0 * xz); by[12] = SH_C3_3 * (-6.0 * yz); bz[12] = SH_C3_3 * (6.0 * zz - 3.0 * xx - 3.0 * yy);
+                    basis[13] = SH_C3_4 * dx * (4.0 * zz - xx - yy);
+                    bx[13] = SH_C3_4 * (4.0 * zz - 3.0 * xx - yy); by[13] = SH_C3_4 * (-2.0 * xy); bz[13] = SH_C3_4 * 8.0 * xz;
+                    basis[14] = SH_C3_5 * dz * (xx - yy);
+                    bx[14] = SH_C3_5 * 2.0 * xz; by[14] = SH_C3_5 * (-2.0 * yz); bz[14] = SH_C3_5 * (xx - yy);
+                    basis[15] = SH_C3_6 * dx * (xx - 3.0 * yy);
+                    bx[15] = SH_C3_6 * (3.0 * xx - 3.0 * yy); by[15] = SH_C3_6 * (-6.0 * xy);
+                }
+            }
+        }
+        const int nb = (cam.degree + 1) * (cam.degree + 1);
+        const float4 *sh4 = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
+        double ddx = 0, ddy = 0, ddz = 0;   // dL/d(dir)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const double dcol = clamped[3 * i + ch] ? 0.0 : (double)dL_dcolors[3 * i + ch];
+            float o[16];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float4 f = sh4[ch * 4 + v];
+                const float coef[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int k = 4 * v + e;
+                    if (k < nb) {
+                        ddx += dcol * bx[k] * (double)coef[e];
+                        ddy += dcol * by[k] * (double)coef[e];
+                        ddz += dcol * bz[k] * (double)coef[e];
+                        o[k] = (float)(dcol * basis[k]);
+                    } else {
+                        o[k] = 0.0f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                float4 w = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
+                if (accumulate) {
+                    const float4 p = out_sh[ch * 4 + v];
+                    w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w;
+                }
+                out_sh[ch * 4 + v] = w;
+            }
+        }
+        // dir = v/|v|: dL/dv = (dL/ddir - dir (dir . dL/ddir)) / |v|   (dnormvdv, setup_gpu.py:256-266)
+        const double dot = dx * ddx + dy * ddy + dz * ddz;
+        g_mean[0] += (ddx - dx * dot) / vn;
+        g_mean[1] += (ddy - dy * dot) / vn;
+        g_mean[2] += (ddz - dz * dot) / vn;
+    } else if (!accumulate) {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int v = 0; v < 12; v++) out_sh[v] = zero;
+    }
+
+    if (accumulate) {
+        if (visible) {
+            for (int k = 0; k < 3; k++) { dL_dmeans[3 * i + k] += (float)g_mean[k]; dL_dlog_scales[3 * i + k] += (float)g_ls[k]; }
+            for (int k = 0; k < 4; k++) dL_dquats[4 * i + k] += (float)g_q[k];
+        }
+    } else {
+        for (int k = 0; k < 3; k++) { dL_dmeans[3 * i + k] = (float)g_mean[k]; dL_dlog_scales[3 * i + k] = (float)g_ls[k]; }
+        for (int k = 0; k < 4; k++) dL_dquats[4 * i + k] = (float)g_q[k];
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_backward_params(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                                  const float *quats, const float *sh, const gs_camera *cam,
+                                  const int32_t *radii, const uint8_t *clamped, const float *dL_dcenters,
+                                  const float *dL_dconics, const float *dL_dcolors, int32_t accumulate,
+                                  float *dL_dmeans, float *dL_dlog_scales, float *dL_dquats, float *dL_dsh) {
+    GS_REQUIRE(ctx && cam, "gs_backward_params: ctx/cam is NULL");
+    GS_REQUIRE(N >= 0, "gs_backward_params: N=%d < 0", N);
+    GS_REQUIRE(cam->sh_degree >= 0 && cam->sh_degree <= 3, "gs_backward_params: sh_degree %d not in 0..3",
+               cam->sh_degree);
+    GS_REQUIRE(cam->res_w > 0 && cam->res_h > 0 && cam->cam_width > 0 && cam->cam_height > 0 && cam->fx > 0 &&
+                   cam->fy > 0, "gs_backward_params: invalid camera/frame description");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(means && log_scales && quats && sh && radii && clamped && dL_dcenters && dL_dconics &&
+                   dL_dcolors && dL_dmeans && dL_dlog_scales && dL_dquats && dL_dsh,
+               "gs_backward_params: NULL array argument");
+    GS_REQUIRE(((uintptr_t)sh & 15) == 0 && ((uintptr_t)dL_dsh & 15) == 0,
+               "gs_backward_params: sh and dL_dsh must be 16-byte aligned");
+    PreCam pc;
+    gs_make_precam(cam, &pc);
+    GS_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(param_bwd_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
+                       log_scales, quats, sh, pc, radii, clamped, dL_dcenters, dL_dconics, dL_dcolors,
+                       accumulate, dL_dmeans, dL_dlog_scales, dL_dquats, dL_dsh);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}

@@ -1,0 +1,139 @@
+"""Device-resident chaining of the hot path for rendering and multi-view training steps.
+
+One view = K1 preprocess -> K2-K5 binning -> K6 blend forward [-> K7 blend backward -> K8
+parameter backward].  Nothing leaves the device between stages (the reference re-uploads every
+array on every call, rasterization.py:44-55, backward_pass.py:106-120).  A training step renders a
+batch of views; with torch.distributed initialised the views are sharded round-robin over the ranks
+(one process per GPU) and the flat per-gaussian gradient buffer [N*59] is summed with ONE
+all-reduce (RCCL over xGMI when the backend is "nccl").  The reference has no counterpart for the
+batch/all-reduce part (its loop is one view per iteration, train.py:18-43).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import api
+from ._lib import check
+
+GRAD_FLOATS = 59   # 3 mean + 3 log-scale + 4 quaternion + 1 opacity + 48 SH
+
+
+class FlatGrads:
+    """One contiguous fp32 buffer [N*59] with per-parameter views, so a single collective moves
+    every gradient."""
+
+    def __init__(self, N, device):
+        self.N = N
+        self.flat = torch.zeros(N * GRAD_FLOATS, dtype=torch.float32, device=device)
+        o = 0
+        self.means = self.flat[o:o + 3 * N].view(N, 3); o += 3 * N
+        self.log_scales = self.flat[o:o + 3 * N].view(N, 3); o += 3 * N
+        self.quats = self.flat[o:o + 4 * N].view(N, 4); o += 4 * N
+        self.opacity = self.flat[o:o + N]; o += N
+        self.sh = self.flat[o:o + 48 * N].view(N, 3, 16)
+
+    def zero_(self):
+        self.flat.zero_()
+
+
+class View:
+    def __init__(self, camera, camera_r, camera_t):
+        self.camera, self.camera_r, self.camera_t = camera, camera_r, camera_t
+
+
+class SplatPipeline:
+    """Holds the parameters on one device and runs views through the native kernels."""
+
+    def __init__(self, gaussians, result_size, tile_size=16, background=(0., 0., 0.), pixel_offset=0.5,
+                 opacity_is_logit=True, ctx=None):
+        self.ctx = api._ctx(ctx)
+        dev = self.ctx.device
+        self.N, self.means, self.log_scales, self.quats, self.sh = api._gaussian_tensors(gaussians, dev)
+        self.opacity = api._dev(gaussians.opacity, torch.float32, dev, (self.N,))
+        self.degrees = int(gaussians.degrees)
+        self.result_size = [int(result_size[0]), int(result_size[1])]
+        self.tile_size = int(tile_size)
+        self.bg = api._bg3(np.asarray(background, dtype=np.float64))
+        self.pixel_offset = float(pixel_offset)
+        self.opacity_is_logit = bool(opacity_is_logit)
+        self.stats = {}
+
+    # ---- forward ------------------------------------------------------------------------
+    def forward(self, view):
+        c = self.ctx
+        c.sync_stream()
+        dev, N, f32, i32 = c.device, self.N, torch.float32, torch.int32
+        W, H = self.result_size
+        cam = api.make_camera(view.camera, view.camera_r, view.camera_t, self.result_size, self.tile_size,
+                              self.degrees)
+        centers = torch.empty((N, 2), dtype=f32, device=dev)
+        depths = torch.empty((N,), dtype=i32, device=dev)
+        colors = torch.empty((N, 3), dtype=f32, device=dev)
+        conics = torch.empty((N, 3), dtype=f32, device=dev)
+        clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev)
+        rect = torch.empty((N, 4), dtype=i32, device=dev)
+        radii = torch.empty((N,), dtype=i32, device=dev)
+        null = ctypes.c_void_p(0)
+        check(c.lib.gs_preprocess(c.handle, N, api._ptr(self.means), api._ptr(self.log_scales),
+                                  api._ptr(self.quats), api._ptr(self.sh), ctypes.byref(cam), api._ptr(centers),
+                                  api._ptr(depths), api._ptr(colors), api._ptr(conics), api._ptr(clamped),
+                                  api._ptr(rect), api._ptr(radii), null, null, null, null, null, null),
+              "gs_preprocess")
+        binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size, self.tile_size)
+        opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
+        image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
+                                                      self.pixel_offset)
+        state = dict(cam=cam, centers=centers, colors=colors, conics=conics, clamped=clamped, radii=radii,
+                     opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final)
+        self.stats = dict(D=binning.D)
+        return image, state
+
+    # ---- backward -----------------------------------------------------------------------
+    def backward(self, state, dL_dimage, grads, accumulate=True):
+        """Accumulates d(loss)/d(parameters) of one view into `grads` (FlatGrads)."""
+        c = self.ctx
+        c.sync_stream()
+        d_centers, d_conics, d_opac, d_colors = api.blend_backward(
+            c, state["centers"], state["colors"], state["opac"], state["conics"], state["binning"], self.bg,
+            self.pixel_offset, state["n_contrib"], state["t_final"], dL_dimage)
+        api.backward_params(c, self.means, self.log_scales, self.quats, self.sh, state["cam"], state["radii"],
+                            state["clamped"], d_centers, d_conics, d_colors,
+                            out=(grads.means, grads.log_scales, grads.quats, grads.sh), accumulate=accumulate)
+        if self.opacity_is_logit:
+            o = state["opac"]
+            d_opac = d_opac * o * (1.0 - o)
+        if accumulate:
+            grads.opacity += d_opac
+        else:
+            grads.opacity.copy_(d_opac)
+        return grads
+
+
+def shard_views(n_views, rank, world_size):
+    """Round-robin view -> rank assignment (view v goes to rank v % world_size)."""
+    return [v for v in range(n_views) if v % world_size == rank]
+
+
+def train_step(pipe, views, targets, grads, loss_scale=None):
+    """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
+    buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
+    match; the loss is mean squared error summed over views.  Returns (sum of local losses as a
+    device scalar, number of local views)."""
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    mine = shard_views(len(views), rank, world)
+    W, H = pipe.result_size
+    scale = (2.0 / (W * H * 3)) if loss_scale is None else loss_scale
+    grads.zero_()
+    loss = torch.zeros((), dtype=torch.float32, device=pipe.ctx.device)
+    for v in mine:
+        image, state = pipe.forward(views[v])
+        diff = image - targets[v]
+        loss = loss + (diff * diff).mean()
+        pipe.backward(state, diff * scale, grads, accumulate=True)
+    if distributed and world > 1:
+        dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
+    return loss, len(mine)

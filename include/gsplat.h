@@ -1,0 +1,133 @@
+/* gsplat.h -- C ABI of libgsplat_hip.so: the MI355X (gfx950) hot path of a 3D Gaussian Splatting
+ * rasteriser, a drop-in for the Python hot-path functions of AubreyFeldker/gaussian-splatting.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the comment says "host";
+ *   - every call is asynchronous on the ctx's HIP stream except where noted (gs_bin_count
+ *     synchronises once to return D);
+ *   - return 0 on success, <0 on error; gs_last_error() returns the message (thread-local);
+ *   - one ctx per stream; calls on one ctx are serialised by the caller; ctxs are independent;
+ *   - images are [W][H][3] x-major exactly as the reference (rasterize.c:93,130,
+ *     rasterization.py:29,96,122);
+ *   - only tile_size == 16 is supported by the blend kernels (rasterize.c:5 TILE_SIZE).
+ *
+ * Each entry point cites the reference interface it replaces (file:line under the reference).
+ */
+#ifndef GSPLAT_H
+#define GSPLAT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gs_ctx gs_ctx;
+
+/* Camera + frame description: the (camera, camera_r, camera_t, result_size, tile_size,
+ * gaussians.degrees) arguments of forward_pass (forward_pass.py:25). Host struct. */
+typedef struct gs_camera {
+    double R[9];          /* camera_r, row-major, as passed to forward_pass                  */
+    double t[3];          /* camera_t                                                         */
+    double fx, fy;        /* camera.params[0], camera.params[1]                               */
+    int32_t cam_width;    /* camera.width  (fov, forward_pass.py:43)                          */
+    int32_t cam_height;   /* camera.height (fov, forward_pass.py:44)                          */
+    int32_t res_w, res_h; /* result_size                                                      */
+    int32_t tile_size;    /* 16                                                               */
+    int32_t sh_degree;    /* gaussians.degrees, 0..3                                          */
+} gs_camera;
+
+/* Replaces setup_gpu() (setup_gpu.py:3-6,370): device context = device id + stream + workspace
+ * arena. `stream` is a hipStream_t (NULL = default stream). */
+int gs_ctx_create(int device, void *stream, gs_ctx **out);
+int gs_ctx_set_stream(gs_ctx *ctx, void *stream);
+int gs_ctx_destroy(gs_ctx *ctx);
+/* Tuning knobs (no reference counterpart).  "pixels_per_thread": 1, 2 or 4 pixels of a tile
+ * column per thread in the blend kernels (default 4 = one wavefront per 16x16 tile; also read
+ * from the environment variable GSPLAT_PPT at ctx creation). */
+int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value);
+const char *gs_last_error(void);
+int gs_version(void);
+
+/* Replaces forward_pass (forward_pass.py:25-136) incl. py_compute_color (:168-215).
+ * Inputs (fp32): means[N,3], log_scales[N,3], quats[N,4] (w,x,y,z), sh[N,3,16].
+ * Outputs: centers[N,2] f32 (pixels), depths[N] i32, colors[N,3] f32, conics[N,3] f32,
+ * clamped[N,3] u8, tiles_touched[N,4] i32 = [xmin,ymin,xmax,ymax] (the reference's [N,2,2]),
+ * radii[N] i32.  The discontinuous chain (depth key, radius, tile rect) is evaluated in fp64 so
+ * the integer outputs equal the reference's.  Training extras (forward_pass.py:89-94,134) are
+ * written when non-NULL: Ws[N,6], Ms[N,9], Ts[N,3], cov2d[N,3], cov3d[N,6], dirs[N,3] (f32). */
+int gs_preprocess(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                  const float *quats, const float *sh, const gs_camera *cam,
+                  float *centers, int32_t *depths, float *colors, float *conics,
+                  uint8_t *clamped, int32_t *tiles_touched, int32_t *radii,
+                  float *Ws, float *Ms, float *Ts, float *cov2d, float *cov3d, float *dirs);
+
+/* Replaces match_gaus_to_tiles (rasterization.py:6-25) + kernel tile_match (setup_gpu.py:23-44)
+ * + the per-tile filter and RadixSort (rasterization.py:57,66-71), in O(D) instead of
+ * O(tiles*N).  Two phases so the caller owns the D-sized outputs:
+ *   gs_bin_count: tiles-per-gaussian + exclusive scan; returns D (host int64; one stream sync).
+ *   gs_bin_fill : duplicate into key=(tile_id<<32)|u32(depth), val=gaussian; stable radix sort;
+ *                 ranges[tile] = [start,end).  tile_id = tx*tiles_y + ty.
+ * Per tile the order is (depth asc, gaussian asc) = the reference's stable low-32-bit sort of
+ * (g<<32)+depth; entries with u32(depth)==0 are dropped (rasterization.py:67).
+ * gs_bin_fill must follow gs_bin_count on the same ctx with the same inputs. */
+int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                 int32_t res_w, int32_t res_h, int32_t tile_size, int64_t *D_host);
+int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                int32_t res_w, int32_t res_h, int32_t tile_size, int64_t D,
+                uint64_t *keys, int32_t *vals, int32_t *ranges);
+
+/* Replaces gpu_rasterize forward (rasterization.py:27-107 + kernel rasterize,
+ * setup_gpu.py:46-100), c_rasterize/rasterize_tile (rasterization.py:109-153, rasterize.c:27-132)
+ * and rasterize (rasterization.py:155-215): one launch for the whole frame.
+ * pixel_offset: dist = c - x + pixel_offset; +0.5 = rasterize.c:103-104, -0.5 =
+ * rasterization.py:187-191, 0 = setup_gpu.py:75-76.
+ * Outputs: image[W,H,3] f32; n_contrib[W,H] i32: bits 0..30 = the reference's
+ * last_contributors (rasterize.c:99-130), bit 31 set iff the pixel left the loop through the
+ * transmittance break (rasterize.c:118-119); t_final[W,H] f32. */
+int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                     const float *opacities, const float *conics, const int32_t *vals,
+                     const int32_t *ranges, int64_t D, const float *background_host3,
+                     int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                     float *image, int32_t *n_contrib, float *t_final);
+
+/* Replaces the backward half of kernel rasterize (setup_gpu.py:105-165, intent; defects B4-B8
+ * not reproduced): reverse-order traversal from each pixel's last contributor.
+ * dL_dimage[W,H,3] is an explicit input (B4).  Outputs are zeroed by the call, then accumulated:
+ * dL_dcenters[N,2] (per pixel unit), dL_dconics[N,3], dL_dopacities[N], dL_dcolors[N,3]. */
+int gs_blend_backward(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                      const float *opacities, const float *conics, const int32_t *vals,
+                      const int32_t *ranges, int64_t D, const float *background_host3,
+                      int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                      const int32_t *n_contrib, const float *t_final, const float *dL_dimage,
+                      float *dL_dcenters, float *dL_dconics, float *dL_dopacities,
+                      float *dL_dcolors);
+
+/* Replaces backward_pass (backward_pass.py:19-68), cov_2d_backpass + kernel cov_2d_grads
+ * (backward_pass.py:99-133, setup_gpu.py:168-253), sh_backpass + kernel sh_grads
+ * (backward_pass.py:70-97, setup_gpu.py:256-303) and the host d_scales/d_rots loop
+ * (backward_pass.py:40-66); intent, defects B3/B9/B10/B13 not reproduced.  Forward
+ * intermediates are recomputed from the parameters (fp64) instead of being re-read.
+ * Inputs: parameters as gs_preprocess; radii[N], clamped[N,3] from gs_preprocess;
+ * dL_dcenters[N,2] (pixel units), dL_dconics[N,3], dL_dcolors[N,3] from gs_blend_backward.
+ * Outputs (written, or += when accumulate != 0): dL_dmeans[N,3], dL_dlog_scales[N,3],
+ * dL_dquats[N,4] (w.r.t. the un-normalised quaternion), dL_dsh[N,3,16]. */
+int gs_backward_params(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                       const float *quats, const float *sh, const gs_camera *cam,
+                       const int32_t *radii, const uint8_t *clamped, const float *dL_dcenters,
+                       const float *dL_dconics, const float *dL_dcolors, int32_t accumulate,
+                       float *dL_dmeans, float *dL_dlog_scales, float *dL_dquats, float *dL_dsh);
+
+/* The reference's only native symbol (rasterize.c:27-28), kept as a compatibility shim with
+ * HOST pointers and `double` conics (defect B7): blends one 16x16 tile on the device through the
+ * same kernel as gs_blend_forward (pixel offset +0.5) and copies the chunk back.  Synchronous.
+ * Returns 0 on success (the original always returns 0, rasterize.c:79), <0 on error. */
+int rasterize_tile(double image_chunk[16][16][3], int last_contributors[16][16],
+                   double centers[][2], double colors[][3], double opacities[],
+                   double conics[][3], int gaus_stack[], double background_color[3],
+                   int stack_size, int training, int tile_x, int tile_y, int result_x,
+                   int result_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_H */
