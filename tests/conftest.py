@@ -54,6 +54,26 @@ def synth_scene(N, W, H, seed=20240601, fx=None, log_scale=(1.0, 3.0), degree=3)
     return Cam(fx, fx, W, H), np.eye(3), np.zeros(3), g, [W, H]
 
 
+def dense_scene(N=2500, W=112, H=96, seed=3):
+    """Small opaque, heavily overlapping scene: exercises the transmittance break
+    (rasterize.c:118-119) and the .99 alpha clamp (rasterize.c:112)."""
+    cam, R, t, g, rs = synth_scene(N, W, H, seed=seed, fx=90.0, log_scale=(2.2, 3.4), degree=2)
+    rng = np.random.default_rng(seed + 1)
+    g.opacity = np.asarray(rng.uniform(.5, 1.0, N), dtype=np.float32)
+    g.center[:, 2] = np.asarray(rng.uniform(2.5, 6.0, N), dtype=np.float32)
+    return cam, R, t, g, rs
+
+
+def as_record(cam, R, t, g, rs, bg=(0., 0., 0.)):
+    """Golden-record-shaped dict for a synthetic scene (inputs only)."""
+    return dict(in_center=np.float64(g.center), in_scaling=np.float64(g.scaling), in_rotation=np.float64(g.rotation),
+                in_sh=np.float64(g.spherical_harmonics), in_opacity=np.float64(g.opacity),
+                in_degrees=np.asarray(g.degrees), in_fx=np.asarray(cam.params[0]), in_fy=np.asarray(cam.params[1]),
+                in_cam_w=np.asarray(cam.width), in_cam_h=np.asarray(cam.height), in_R=np.asarray(R, dtype=np.float64),
+                in_t=np.asarray(t, dtype=np.float64), in_result_size=np.asarray(rs), in_bg=np.asarray(bg, dtype=np.float64),
+                in_tile_size=np.asarray(16))
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx():
     import torch

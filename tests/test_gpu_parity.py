@@ -10,7 +10,7 @@ by the fp64 oracle, must be rare (<0.5 % of pixels) and are excluded from the ma
 import numpy as np
 import pytest
 
-from conftest import load_scene, scene_inputs, synth_scene
+from conftest import as_record, dense_scene, load_scene, scene_inputs, synth_scene
 from oracle import cref, ref_np, ref_torch
 
 pytestmark = pytest.mark.gpu
@@ -151,7 +151,7 @@ def test_blend_forward_state_vs_c_oracle(gpu_ctx, offset):
     """image, last_contributors (rasterize.c:99-130) and final transmittance vs the C restatement
     fed with the same fp32-rounded inputs."""
     import gsplat_amd as gs
-    d = load_scene("s1")
+    d = as_record(*dense_scene(), bg=(.2, .1, .3))
     cam, R, t, g, rs, bg = scene_inputs(d)
     centers, depths, colors, conics, tiles_touched, radii = _fwd(gpu_ctx, d, training=False)
     b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tiles_touched, radii, depths, result_size=rs)
@@ -166,7 +166,7 @@ def test_blend_forward_state_vs_c_oracle(gpu_ctx, offset):
     nc = n_contrib.cpu().numpy()
     assert np.array_equal((nc & 0x7FFFFFFF)[ok], lc[ok])
     np.testing.assert_allclose(t_final.cpu().numpy()[ok], tf[ok], rtol=1e-4, atol=1e-7)
-    assert (nc < 0).any(), "scene should exercise the transmittance break"
+    assert (nc < 0).mean() > 0.1, "scene should exercise the transmittance break"
 
 
 def test_c_rasterize_shim_matches_c_oracle(gpu_ctx):
@@ -223,7 +223,8 @@ def _assert_grad(got, ref, what, tol=GRAD_TOL):
     assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
 
 
-@pytest.mark.parametrize("name,ppt", [("s1", 4), ("s3", 4), ("s1", 1), ("s3", 2), ("s2", 4)])
+@pytest.mark.parametrize("name,ppt", [("s1", 4), ("s3", 4), ("s1", 1), ("s3", 2), ("s2", 4), ("dense", 4),
+                                      ("dense", 1)])
 def test_gradients_vs_fp64_autograd(gpu_ctx, name, ppt):
     """K7 (blend backward) and K8 (parameter backward) through the reference-shaped API against
     float64 autograd of the oracle forward.  Gradients are "parity unpinned by the reference": its
@@ -231,7 +232,7 @@ def test_gradients_vs_fp64_autograd(gpu_ctx, name, ppt):
     import gsplat_amd as gs
     gpu_ctx.set_option("pixels_per_thread", ppt)
     try:
-        d = load_scene(name)
+        d = as_record(*dense_scene(), bg=(.2, .1, .3)) if name == "dense" else load_scene(name)
         cam, R, t, g, rs, bg = scene_inputs(d)
         rng = np.random.default_rng(7)
         wimg = rng.normal(size=(rs[0], rs[1], 3)).astype(np.float32)
@@ -301,9 +302,11 @@ def test_pipeline_matches_stage_api_and_is_linear(gpu_ctx):
     lin = 2.0 * ga.flat - 0.5 * gb.flat
     scale = lin.abs().max().item()
     assert scale > 0 and (gc.flat - lin).abs().max().item() <= 2e-5 * scale
-    # accumulate=True adds
+    # accumulate=True adds on top
+    before = ga.flat.clone()
     pipe.backward(state, d2, ga, accumulate=True)
-    assert (ga.flat - (lin + 0.5 * gb.flat - 2.0 * (ga.flat - gb.flat - gb.flat * 0) + 2.0 * (ga.flat - gb.flat))).abs().max() >= 0
+    want = before + gb.flat
+    assert (ga.flat - want).abs().max().item() <= 2e-5 * want.abs().max().item()
 
 
 def test_full_size_properties(gpu_ctx):
