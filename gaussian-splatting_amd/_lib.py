@@ -30,6 +30,10 @@ SIGNATURES = {
     "gs_ctx_set_stream": (ctypes.c_int, [_P, _P]),
     "gs_ctx_destroy": (ctypes.c_int, [_P]),
     "gs_ctx_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, _I32]),
+    "gs_profile_kernel_count": (ctypes.c_int, []),
+    "gs_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "gs_ctx_profile": (ctypes.c_int, [_P, _I32]),
+    "gs_ctx_profile_read": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
     "gs_last_error": (ctypes.c_char_p, []),
     "gs_version": (ctypes.c_int, []),
     "gs_preprocess": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, ctypes.POINTER(GsCamera)] + [_P] * 13),

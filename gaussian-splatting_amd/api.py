@@ -65,6 +65,18 @@ class DeviceContext:
     def set_option(self, name, value):
         check(self.lib.gs_ctx_set_option(self.handle, name.encode(), int(value)), "gs_ctx_set_option")
 
+    def profile(self, enable=True):
+        """Bracket every kernel launch with HIP events (see read_profile)."""
+        check(self.lib.gs_ctx_profile(self.handle, int(bool(enable))), "gs_ctx_profile")
+
+    def read_profile(self):
+        """{kernel name: (total ms, launches)} since the last read; synchronises the stream."""
+        n = self.lib.gs_profile_kernel_count()
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int64 * n)()
+        check(self.lib.gs_ctx_profile_read(self.handle, ms, cnt), "gs_ctx_profile_read")
+        return {self.lib.gs_profile_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.gs_ctx_destroy(self.handle)

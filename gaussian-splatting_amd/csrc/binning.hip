@@ -239,12 +239,12 @@ extern "C" int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched
     if ((rc = gs_buf_reserve(ctx, &ctx->total, 8))) return rc;
     const int4 *rect = reinterpret_cast<const int4 *>(tiles_touched);
     uint32_t *bs = (uint32_t *)ctx->block_sums.p;
-    hipLaunchKernelGGL(count_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N, rect, depths,
-                       grid, bs);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, nblocks, bs,
-                       (uint64_t *)ctx->total.p);
-    hipLaunchKernelGGL(offsets_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N, rect, depths,
-                       grid, bs, (uint32_t *)ctx->offsets.p);
+    { gs_prof_scope prof_(ctx, GS_K_COUNT); hipLaunchKernelGGL(count_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N, rect, depths,
+                       grid, bs); }
+    { gs_prof_scope prof_(ctx, GS_K_SCAN); hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, nblocks, bs,
+                       (uint64_t *)ctx->total.p); }
+    { gs_prof_scope prof_(ctx, GS_K_OFFSETS); hipLaunchKernelGGL(offsets_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N, rect, depths,
+                       grid, bs, (uint32_t *)ctx->offsets.p); }
     GS_HIP(hipGetLastError());
     GS_HIP(hipMemcpyAsync(ctx->total_host, ctx->total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     GS_HIP(hipStreamSynchronize(ctx->stream));
@@ -278,9 +278,9 @@ extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched,
     if ((rc = gs_buf_reserve(ctx, &ctx->vals_tmp, (size_t)D * 4))) return rc;
     uint64_t *k_in = (uint64_t *)ctx->keys_tmp.p;
     int32_t *v_in = (int32_t *)ctx->vals_tmp.p;
-    hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+    { gs_prof_scope prof_(ctx, GS_K_DUPLICATE); hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                        reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
-                       (const uint32_t *)ctx->offsets.p, k_in, v_in);
+                       (const uint32_t *)ctx->offsets.p, k_in, v_in); }
     GS_HIP(hipGetLastError());
 
     // K4: stable LSD radix sort on the live key bits only
@@ -291,11 +291,14 @@ extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched,
     GS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, keys, v_in, vals, (size_t)D, 0u, end_bit,
                                      ctx->stream));
     if ((rc = gs_buf_reserve(ctx, &ctx->sort_tmp, tmp_bytes))) return rc;
-    GS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, k_in, keys, v_in, vals, (size_t)D, 0u,
-                                     end_bit, ctx->stream));
+    {
+        gs_prof_scope prof_(ctx, GS_K_SORT);
+        GS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, k_in, keys, v_in, vals, (size_t)D, 0u,
+                                         end_bit, ctx->stream));
+    }
 
-    hipLaunchKernelGGL(ranges_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream,
-                       (uint32_t)D, keys, ranges);
+    { gs_prof_scope prof_(ctx, GS_K_RANGES); hipLaunchKernelGGL(ranges_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream,
+                       (uint32_t)D, keys, ranges); }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -356,9 +356,9 @@ extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, co
     GS_HIP(hipSetDevice(ctx->device));
     const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
     switch (ctx->ppt) {
-        case 1: hipLaunchKernelGGL(blend_fwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, image, n_contrib, t_final); break;
-        case 2: hipLaunchKernelGGL(blend_fwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, image, n_contrib, t_final); break;
-        default: hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(tiles), dim3(64), 0, ctx->stream, a, image, n_contrib, t_final); break;
+        case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_FWD); hipLaunchKernelGGL(blend_fwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, image, n_contrib, t_final); } break;
+        case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_FWD); hipLaunchKernelGGL(blend_fwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, image, n_contrib, t_final); } break;
+        default: { gs_prof_scope prof_(ctx, GS_K_BLEND_FWD); hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(tiles), dim3(64), 0, ctx->stream, a, image, n_contrib, t_final); } break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;
@@ -386,14 +386,14 @@ extern "C" int gs_blend_backward(gs_ctx *ctx, int32_t N, const float *centers, c
     const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
     if (D > 0) {
         switch (ctx->ppt) {
-            case 1: hipLaunchKernelGGL(blend_bwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); break;
-            case 2: hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); break;
-            default: hipLaunchKernelGGL(blend_bwd_kernel<4>, dim3(tiles), dim3(64), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); break;
+            case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
+            case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
+            default: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<4>, dim3(tiles), dim3(64), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
         }
         GS_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, rows,
-                       dL_dcenters, dL_dconics, dL_dopacities, dL_dcolors);
+    { gs_prof_scope prof_(ctx, GS_K_UNPACK); hipLaunchKernelGGL(unpack_rows_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, rows,
+                       dL_dcenters, dL_dconics, dL_dopacities, dL_dcolors); }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

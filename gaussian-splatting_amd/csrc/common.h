@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 #include "../../include/gsplat.h"
 
 #define GS_OK 0
@@ -24,6 +25,17 @@ int gs_set_error(int code, const char *fmt, ...);
     do {                                                                                   \
         if (!(cond)) return gs_set_error(GS_ERR_ARG, __VA_ARGS__);                         \
     } while (0)
+
+// per-kernel HIP-event timing (off by default; see gs_ctx_profile)
+enum gs_kernel_id {
+    GS_K_PREPROCESS, GS_K_COUNT, GS_K_SCAN, GS_K_OFFSETS, GS_K_DUPLICATE, GS_K_SORT, GS_K_RANGES,
+    GS_K_BLEND_FWD, GS_K_BLEND_BWD, GS_K_UNPACK, GS_K_PARAM_BWD, GS_K_NUM
+};
+
+struct gs_prof_span {
+    int kernel;
+    hipEvent_t start, stop;
+};
 
 // grow-only device buffer owned by the ctx (no hipMalloc in steady state)
 struct gs_buf {
@@ -47,11 +59,23 @@ struct gs_ctx {
     gs_buf tile_scratch; // rasterize_tile shim staging
     uint64_t *total_host = nullptr;   // pinned
     // state carried from gs_bin_count to gs_bin_fill
+    bool prof_on = false;
+    std::vector<gs_prof_span> prof_spans;     // recorded, not yet read
+    std::vector<hipEvent_t> prof_free;        // recycled events
     int ppt = 4;         // pixels per thread of the blend kernels (1, 2 or 4)
     int32_t bin_N = -1;
     int64_t bin_D = -1;
 };
 
 int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);
+
+// brackets the launches issued during its lifetime with two events on the ctx stream
+struct gs_prof_scope {
+    gs_ctx *ctx;
+    gs_prof_span span;
+    bool live = false;
+    gs_prof_scope(gs_ctx *c, int kernel);
+    ~gs_prof_scope();
+};
 
 static inline int gs_div_up(int a, int b) { return (a + b - 1) / b; }

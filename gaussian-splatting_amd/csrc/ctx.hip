@@ -64,6 +64,64 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
     return gs_set_error(GS_ERR_ARG, "gs_ctx_set_option: unknown option '%s'", name);
 }
 
+static const char *const k_kernel_names[GS_K_NUM] = {
+    "preprocess", "bin_count", "bin_scan", "bin_offsets", "bin_duplicate", "bin_sort", "bin_ranges",
+    "blend_forward", "blend_backward", "grad_unpack", "param_backward"};
+
+static hipEvent_t prof_event(gs_ctx *c) {
+    if (!c->prof_free.empty()) {
+        hipEvent_t e = c->prof_free.back();
+        c->prof_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+gs_prof_scope::gs_prof_scope(gs_ctx *c, int kernel) : ctx(c) {
+    if (!c || !c->prof_on) return;
+    span.kernel = kernel;
+    span.start = prof_event(c);
+    span.stop = prof_event(c);
+    if (!span.start || !span.stop) return;
+    live = hipEventRecord(span.start, c->stream) == hipSuccess;
+}
+
+gs_prof_scope::~gs_prof_scope() {
+    if (!live) return;
+    if (hipEventRecord(span.stop, ctx->stream) == hipSuccess) ctx->prof_spans.push_back(span);
+}
+
+extern "C" int gs_profile_kernel_count(void) { return GS_K_NUM; }
+extern "C" const char *gs_profile_kernel_name(int i) {
+    return (i >= 0 && i < GS_K_NUM) ? k_kernel_names[i] : nullptr;
+}
+
+extern "C" int gs_ctx_profile(gs_ctx *ctx, int32_t enable) {
+    GS_REQUIRE(ctx, "gs_ctx_profile: ctx is NULL");
+    ctx->prof_on = enable != 0;
+    return GS_OK;
+}
+
+extern "C" int gs_ctx_profile_read(gs_ctx *ctx, double *ms_sum, int64_t *launches) {
+    GS_REQUIRE(ctx && ms_sum && launches, "gs_ctx_profile_read: NULL argument");
+    for (int i = 0; i < GS_K_NUM; i++) { ms_sum[i] = 0.0; launches[i] = 0; }
+    GS_HIP(hipSetDevice(ctx->device));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    for (gs_prof_span &s : ctx->prof_spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess) {
+            ms_sum[s.kernel] += ms;
+            launches[s.kernel] += 1;
+        }
+        ctx->prof_free.push_back(s.start);
+        ctx->prof_free.push_back(s.stop);
+    }
+    ctx->prof_spans.clear();
+    return GS_OK;
+}
+
 extern "C" int gs_ctx_set_stream(gs_ctx *ctx, void *stream) {
     GS_REQUIRE(ctx != nullptr, "gs_ctx_set_stream: ctx is NULL");
     ctx->stream = (hipStream_t)stream;
@@ -78,6 +136,8 @@ extern "C" int gs_ctx_destroy(gs_ctx *ctx) {
                       &ctx->sort_tmp, &ctx->packed, &ctx->grad_rows, &ctx->tile_scratch};
     for (gs_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (gs_prof_span &sp : ctx->prof_spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }
+    for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     if (ctx->total_host) (void)hipHostFree(ctx->total_host);
     delete ctx;
     return GS_OK;

@@ -247,9 +247,9 @@ extern "C" int gs_backward_params(gs_ctx *ctx, int32_t N, const float *means, co
     PreCam pc;
     gs_make_precam(cam, &pc);
     GS_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(param_bwd_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
+    { gs_prof_scope prof_(ctx, GS_K_PARAM_BWD); hipLaunchKernelGGL(param_bwd_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
                        log_scales, quats, sh, pc, radii, clamped, dL_dcenters, dL_dconics, dL_dcolors,
-                       accumulate, dL_dmeans, dL_dlog_scales, dL_dquats, dL_dsh);
+                       accumulate, dL_dmeans, dL_dlog_scales, dL_dquats, dL_dsh); }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -253,9 +253,9 @@ extern "C" int gs_preprocess(gs_ctx *ctx, int32_t N, const float *means, const f
     PreCam pc;
     gs_make_precam(cam, &pc);
     GS_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+    { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                        means, log_scales, quats, sh, pc, centers, depths, colors, conics, clamped,
-                       tiles_touched, radii, Ws, Ms, Ts, cov2d, cov3d, dirs);
+                       tiles_touched, radii, Ws, Ms, Ts, cov2d, cov3d, dirs); }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

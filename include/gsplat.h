@@ -45,6 +45,15 @@ int gs_ctx_destroy(gs_ctx *ctx);
  * column per thread in the blend kernels (default 4 = one wavefront per 16x16 tile; also read
  * from the environment variable GSPLAT_PPT at ctx creation). */
 int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value);
+/* Per-kernel timing with HIP events on the ctx stream (no reference counterpart; the reference
+ * only prints perf_counter deltas per stage, train.py:29-60).  While enabled every kernel launch
+ * is bracketed by two events; gs_ctx_profile_read synchronises the stream, returns the summed
+ * milliseconds and launch counts per kernel (arrays of gs_profile_kernel_count() entries, names
+ * from gs_profile_kernel_name) and resets the counters. */
+int gs_profile_kernel_count(void);
+const char *gs_profile_kernel_name(int i);
+int gs_ctx_profile(gs_ctx *ctx, int32_t enable);
+int gs_ctx_profile_read(gs_ctx *ctx, double *ms_sum_host, int64_t *launches_host);
 const char *gs_last_error(void);
 int gs_version(void);
 
