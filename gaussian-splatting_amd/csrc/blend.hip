@@ -306,6 +306,349 @@ __global__ __launch_bounds__(256 / PPT) void blend_bwd_kernel(BlendArgs a, const
     }
 }
 
+// ------------------------------------------------------------------------------ K6/K7, v2
+// One wave64 per 16x16 tile, 4 pixels per lane arranged as the four 8x8 quadrants of the tile
+// (lane = 8*qx + qy owns (qx,qy), (qx,qy+8), (qx+8,qy), (qx+8,qy+8)), so that "no lane of the
+// wave needs slot k" is an 8x8-granular cull decided by one ballot.  Per-gaussian records are
+// packed once per launch (pack_kernel) with the conic pre-scaled to log2 units, so
+// G = 2^(a' dx^2 + b' dx dy + c' dy^2) is one v_exp_f32, plus a per-gaussian threshold
+// tau = log2(ALPHA_MIN / opacity) - margin: a pair with power2 <= tau cannot reach alpha >= 1/255
+// (rasterize.c:114) and is skipped without evaluating the exponential.  While staging a 64-entry
+// batch into LDS each lane tests its entry against the whole tile (exact minimum of the quadratic
+// over the tile's pixel box) and the batch is compacted with a ballot; skipped entries change no
+// pixel, and `last_contributors` keeps counting them because every staged entry carries its
+// original list index.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float TAU_MARGIN = 0.02f;    // log2 units: 1.4 % in alpha, far above fp32 error
+
+struct QuadArgs {
+    const float4 *geo;    // cx, cy, opacity, tau
+    const float4 *con;    // a', b', c', 0   (log2-scaled: power2 = a' dx^2 + b' dx dy + c' dy^2)
+    const float4 *rgb;
+    const int32_t *vals;
+    const int2 *ranges;
+    float bg[3];
+    int W, H, tiles_y;
+    float pixel_offset;
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(int N, const float2 *__restrict__ centers,
+                                                   const float *__restrict__ colors,
+                                                   const float *__restrict__ opacities,
+                                                   const float *__restrict__ conics, float4 *__restrict__ geo,
+                                                   float4 *__restrict__ con, float4 *__restrict__ rgb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float2 c = centers[i];
+    const float o = opacities[i];
+    const float tau = (o > 0.0f) ? (__log2f(ALPHA_MIN / o) - TAU_MARGIN) : 1e30f;
+    geo[i] = make_float4(c.x, c.y, o, tau);
+    con[i] = make_float4(-0.5f * LOG2E * conics[3 * i], -LOG2E * conics[3 * i + 1],
+                         -0.5f * LOG2E * conics[3 * i + 2], 0.0f);
+    rgb[i] = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.0f);
+}
+
+// max over the tile's pixel box of power2 >= tau ?  u = cx - x in [ulo,uhi], v likewise.
+// Q = alpha u^2 + beta u v + gamma v^2 is convex; outside the origin its box minimum lies on one
+// of the four edges.  NaNs (degenerate conics) fall through to "keep".
+__device__ __forceinline__ bool tile_may_contribute(const float4 geo, const float4 con, float xlo, float xhi,
+                                                    float ylo, float yhi) {
+    const float ulo = geo.x - xhi, uhi = geo.x - xlo, vlo = geo.y - yhi, vhi = geo.y - ylo;
+    const float al = -con.x, be = -con.y, ga = -con.z;
+    float qmin;
+    if (ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f) {
+        qmin = 0.0f;
+    } else {
+        const float inv2g = 0.5f / ga, inv2a = 0.5f / al;
+        float v = fminf(fmaxf(-be * ulo * inv2g, vlo), vhi);
+        float q0 = al * ulo * ulo + (be * ulo + ga * v) * v;
+        v = fminf(fmaxf(-be * uhi * inv2g, vlo), vhi);
+        float q1 = al * uhi * uhi + (be * uhi + ga * v) * v;
+        float u = fminf(fmaxf(-be * vlo * inv2a, ulo), uhi);
+        float q2 = ga * vlo * vlo + (be * vlo + al * u) * u;
+        u = fminf(fmaxf(-be * vhi * inv2a, ulo), uhi);
+        float q3 = ga * vhi * vhi + (be * vhi + al * u) * u;
+        qmin = fminf(fminf(q0, q1), fminf(q2, q3));
+    }
+    // relative slack on qmin covers the rounding of the edge evaluation itself
+    return !(-qmin * 0.999f + 1e-4f < geo.w);
+}
+
+__global__ __launch_bounds__(64) void blend_fwd_quad_kernel(QuadArgs a, float *__restrict__ image,
+                                                            int32_t *__restrict__ n_contrib,
+                                                            float *__restrict__ t_final) {
+    __shared__ float4 s_geo[64];
+    __shared__ float4 s_con[64];
+    __shared__ float4 s_rgb[64];
+    __shared__ int s_idx[64];
+
+    const int tile = blockIdx.x;
+    const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
+    const int lane = threadIdx.x;
+    const int qy = lane & 7, qx = lane >> 3;
+    const int X0 = tx * TILE, Y0 = ty * TILE;
+    const float off = a.pixel_offset;
+    const float fx0 = (float)(X0 + qx) - off, fx1 = fx0 + 8.0f;
+    const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
+    const float xlo = (float)X0 - off, xhi = xlo + 15.0f, ylo = (float)Y0 - off, yhi = ylo + 15.0f;
+    const int2 rg = a.ranges[tile];
+    const int len = rg.y - rg.x;
+
+    float T[4], C[4][3];
+    int last[4];
+    bool done[4], broke[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int px = X0 + qx + 8 * (k >> 1), py = Y0 + qy + 8 * (k & 1);
+        T[k] = 1.0f;
+        C[k][0] = C[k][1] = C[k][2] = 0.0f;
+        last[k] = len;
+        broke[k] = false;
+        done[k] = !(px < a.W && py < a.H);
+    }
+
+    for (int base = 0; base < len; base += 64) {
+        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        __syncthreads();
+        const int i = base + lane;
+        bool keep = false;
+        float4 geo, con;
+        int g = 0;
+        if (i < len) {
+            g = a.vals[rg.x + i];
+            geo = a.geo[g];
+            con = a.con[g];
+            keep = tile_may_contribute(geo, con, xlo, xhi, ylo, yhi);
+        }
+        const unsigned long long m = __ballot(keep);
+        const int n = __popcll(m);
+        if (keep) {
+            const int pos = __popcll(m & ((1ull << lane) - 1ull));
+            s_geo[pos] = geo;
+            s_con[pos] = con;
+            s_rgb[pos] = a.rgb[g];
+            s_idx[pos] = i;
+        }
+        __syncthreads();
+
+        for (int j = 0; j < n; j++) {
+            const float4 ge = s_geo[j];
+            const float4 co = s_con[j];
+            const float dx0 = ge.x - fx0, dx1 = ge.x - fx1, dy0 = ge.y - fy0, dy1 = ge.y - fy1;
+            const float adx0 = co.x * dx0, adx1 = co.x * dx1;
+            const float cyy0 = co.z * dy0 * dy0, cyy1 = co.z * dy1 * dy1;
+            float p[4];
+            p[0] = __builtin_fmaf(dx0, __builtin_fmaf(co.y, dy0, adx0), cyy0);
+            p[1] = __builtin_fmaf(dx0, __builtin_fmaf(co.y, dy1, adx0), cyy1);
+            p[2] = __builtin_fmaf(dx1, __builtin_fmaf(co.y, dy0, adx1), cyy0);
+            p[3] = __builtin_fmaf(dx1, __builtin_fmaf(co.y, dy1, adx1), cyy1);
+            bool cand[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cand[k] = !done[k] && p[k] > ge.w;
+            if (!__any(cand[0] || cand[1] || cand[2] || cand[3])) continue;
+            const float4 rgb = s_rgb[j];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!__any(cand[k])) continue;
+                const float G = __builtin_amdgcn_exp2f(p[k]);
+                const float alpha = fminf(ALPHA_MAX, ge.z * G);
+                const bool valid = cand[k] && !(p[k] > 0.0f) && !(alpha < ALPHA_MIN);
+                float w = valid ? alpha * T[k] : 0.0f;
+                float tT = T[k] - w;
+                const bool brk = tT < T_MIN;
+                if (__any(brk)) {   // rare: at most once per pixel
+                    w = brk ? 0.0f : w;
+                    tT = brk ? T[k] : tT;
+                    last[k] = brk ? s_idx[j] + 1 : last[k];
+                    done[k] = done[k] || brk;
+                    broke[k] = broke[k] || brk;
+                }
+                C[k][0] = __builtin_fmaf(rgb.x, w, C[k][0]);
+                C[k][1] = __builtin_fmaf(rgb.y, w, C[k][1]);
+                C[k][2] = __builtin_fmaf(rgb.z, w, C[k][2]);
+                T[k] = tT;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int px = X0 + qx + 8 * (k >> 1), py = Y0 + qy + 8 * (k & 1);
+        if (px < a.W && py < a.H) {
+            const size_t pidx = (size_t)px * a.H + py;
+            image[3 * pidx] = __builtin_fmaf(a.bg[0], T[k], C[k][0]);
+            image[3 * pidx + 1] = __builtin_fmaf(a.bg[1], T[k], C[k][1]);
+            image[3 * pidx + 2] = __builtin_fmaf(a.bg[2], T[k], C[k][2]);
+            n_contrib[pidx] = last[k] | (broke[k] ? (int32_t)0x80000000 : 0);
+            t_final[pidx] = T[k];
+        }
+    }
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void blend_bwd_quad_kernel(QuadArgs a, const int32_t *__restrict__ n_contrib,
+                                                            const float *__restrict__ t_final,
+                                                            const float *__restrict__ dL_dimage,
+                                                            float *__restrict__ grad_rows) {
+    __shared__ float4 s_geo[64];
+    __shared__ float4 s_con[64];
+    __shared__ float4 s_rgb[64];
+    __shared__ int s_idx[64];
+    __shared__ int s_g[64];
+    __shared__ __align__(16) float s_grad[64][12];
+
+    const int tile = blockIdx.x;
+    const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
+    const int lane = threadIdx.x;
+    const int qy = lane & 7, qx = lane >> 3;
+    const int X0 = tx * TILE, Y0 = ty * TILE;
+    const float off = a.pixel_offset;
+    const float fx0 = (float)(X0 + qx) - off, fx1 = fx0 + 8.0f;
+    const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
+    const float xlo = (float)X0 - off, xhi = xlo + 15.0f, ylo = (float)Y0 - off, yhi = ylo + 15.0f;
+    const int2 rg = a.ranges[tile];
+
+    // per pixel: transmittance T (walked backwards by division), dL/dpixel, and the running
+    // scalar s = T_final*(bg.dL) + sum_{k behind} w_k (c_k.dL)  (what sits behind the current
+    // gaussian, already contracted with dL/dpixel)
+    float T[4], sacc[4], dLp[4][3];
+    int end_k[4];
+    int my_max = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int px = X0 + qx + 8 * (k >> 1), py = Y0 + qy + 8 * (k & 1);
+        end_k[k] = 0;
+        T[k] = 1.0f;
+        sacc[k] = 0.0f;
+        dLp[k][0] = dLp[k][1] = dLp[k][2] = 0.0f;
+        if (px < a.W && py < a.H) {
+            const size_t pidx = (size_t)px * a.H + py;
+            const int32_t nc = n_contrib[pidx];
+            const int cnt = nc & 0x7fffffff;
+            end_k[k] = (nc < 0) ? cnt - 1 : cnt;   // the breaking entry was not blended
+            T[k] = t_final[pidx];
+            dLp[k][0] = dL_dimage[3 * pidx];
+            dLp[k][1] = dL_dimage[3 * pidx + 1];
+            dLp[k][2] = dL_dimage[3 * pidx + 2];
+            sacc[k] = T[k] * (a.bg[0] * dLp[k][0] + a.bg[1] * dLp[k][1] + a.bg[2] * dLp[k][2]);
+        }
+        my_max = max(my_max, end_k[k]);
+    }
+    const int max_end = wave_max_i32(my_max);
+
+    const int nbatch = (max_end + 63) / 64;
+    for (int b = nbatch - 1; b >= 0; b--) {
+        const int base = b * 64;
+        __syncthreads();
+        const int i = base + lane;
+        bool keep = false;
+        float4 geo, con;
+        int g = 0;
+        if (i < max_end) {
+            g = a.vals[rg.x + i];
+            geo = a.geo[g];
+            con = a.con[g];
+            keep = tile_may_contribute(geo, con, xlo, xhi, ylo, yhi);
+        }
+        const unsigned long long m = __ballot(keep);
+        const int n = __popcll(m);
+        if (keep) {
+            const int pos = __popcll(m & ((1ull << lane) - 1ull));
+            s_geo[pos] = geo;
+            s_con[pos] = con;
+            s_rgb[pos] = a.rgb[g];
+            s_idx[pos] = i;
+            s_g[pos] = g;
+        }
+        __syncthreads();
+
+        unsigned long long touched = 0ull;   // wave-uniform: entries that received a gradient
+        for (int j = n - 1; j >= 0; j--) {
+            const float4 ge = s_geo[j];
+            const float4 co = s_con[j];
+            const int idx = s_idx[j];
+            const float dx0 = ge.x - fx0, dx1 = ge.x - fx1, dy0 = ge.y - fy0, dy1 = ge.y - fy1;
+            const float adx0 = co.x * dx0, adx1 = co.x * dx1;
+            const float cdy0 = co.z * dy0, cdy1 = co.z * dy1;
+            const float cyy0 = cdy0 * dy0, cyy1 = cdy1 * dy1;
+            float tt[4], p[4];
+            tt[0] = __builtin_fmaf(co.y, dy0, adx0);
+            tt[1] = __builtin_fmaf(co.y, dy1, adx0);
+            tt[2] = __builtin_fmaf(co.y, dy0, adx1);
+            tt[3] = __builtin_fmaf(co.y, dy1, adx1);
+            p[0] = __builtin_fmaf(dx0, tt[0], cyy0);
+            p[1] = __builtin_fmaf(dx0, tt[1], cyy1);
+            p[2] = __builtin_fmaf(dx1, tt[2], cyy0);
+            p[3] = __builtin_fmaf(dx1, tt[3], cyy1);
+            bool cand[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cand[k] = idx < end_k[k] && p[k] > ge.w;
+            if (!__any(cand[0] || cand[1] || cand[2] || cand[3])) continue;
+            const float4 rgb = s_rgb[j];
+            float g_cx = 0.f, g_cy = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+            bool any_valid = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!__any(cand[k])) continue;
+                const float dx = (k >> 1) ? dx1 : dx0, dy = (k & 1) ? dy1 : dy0;
+                const float adx = (k >> 1) ? adx1 : adx0, cdy = (k & 1) ? cdy1 : cdy0;
+                const float G = __builtin_amdgcn_exp2f(p[k]);
+                const float araw = ge.z * G;
+                const float alpha = fminf(ALPHA_MAX, araw);
+                const bool valid = cand[k] && !(p[k] > 0.0f) && !(alpha < ALPHA_MIN);
+                if (!__any(valid)) continue;
+                any_valid = true;
+                const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float Tn = T[k] * inv;              // transmittance in front of this gaussian
+                T[k] = valid ? Tn : T[k];
+                const float w = valid ? alpha * Tn : 0.0f;
+                const float cd = __builtin_fmaf(rgb.z, dLp[k][2], __builtin_fmaf(rgb.y, dLp[k][1], rgb.x * dLp[k][0]));
+                const float dLda = __builtin_fmaf(Tn, cd, -sacc[k] * inv);
+                sacc[k] = __builtin_fmaf(w, cd, sacc[k]);
+                g_r = __builtin_fmaf(w, dLp[k][0], g_r);
+                g_g = __builtin_fmaf(w, dLp[k][1], g_g);
+                g_b = __builtin_fmaf(w, dLp[k][2], g_b);
+                // min(.99, .) passes no gradient where the clamp is active
+                const float dm = (valid && !(araw > ALPHA_MAX)) ? dLda : 0.0f;
+                g_o = __builtin_fmaf(G, dm, g_o);
+                const float q = araw * dm;                 // dL/dG * G
+                g_cx = __builtin_fmaf(q, tt[k] + adx, g_cx);                        // 2a'dx + b'dy
+                g_cy = __builtin_fmaf(q, __builtin_fmaf(co.y, dx, cdy) + cdy, g_cy); // 2c'dy + b'dx
+                g_A = __builtin_fmaf(q, dx * dx, g_A);
+                g_B = __builtin_fmaf(q, dx * dy, g_B);
+                g_C = __builtin_fmaf(q, dy * dy, g_C);
+            }
+            if (!any_valid) continue;    // wave-uniform
+            g_cx = wave_sum_to_lane63(g_cx); g_cy = wave_sum_to_lane63(g_cy);
+            g_A = wave_sum_to_lane63(g_A); g_B = wave_sum_to_lane63(g_B); g_C = wave_sum_to_lane63(g_C);
+            g_o = wave_sum_to_lane63(g_o);
+            g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+            touched |= 1ull << j;
+            if (lane == 63) {
+                // undo the log2 pre-scaling: d power/d(.) = ln2 * d power2/d(.)
+                *reinterpret_cast<float4 *>(&s_grad[j][0]) = make_float4(LN2 * g_cx, LN2 * g_cy, -0.5f * g_A, -g_B);
+                *reinterpret_cast<float4 *>(&s_grad[j][4]) = make_float4(-0.5f * g_C, g_o, g_r, g_g);
+                s_grad[j][8] = g_b;
+            }
+        }
+        __syncthreads();
+        // flush: one 64-byte row per gaussian, 4 rows per wave-instruction, lanes 0..8 of each
+        // 16-lane group active -> one memory-side atomic request per (tile, gaussian)
+        const int comp = lane & 15;
+        for (int e0 = 0; e0 < n; e0 += 4) {
+            const int e = e0 + (lane >> 4);
+            if (e < n && comp < 9 && ((touched >> e) & 1ull))
+                atomicAdd(&grad_rows[(size_t)s_g[e] * GRAD_ROW + comp], s_grad[e][comp]);
+        }
+    }
+}
+
 // grad rows -> the reference's four arrays (gpu_rasterize return tuple, rasterization.py:105)
 __global__ __launch_bounds__(256) void unpack_rows_kernel(int N, const float *__restrict__ rows,
                                                           float *__restrict__ d_centers, float *__restrict__ d_conics,
@@ -319,6 +662,24 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(int N, const float *__
     d_conics[3 * i] = r0.z; d_conics[3 * i + 1] = r0.w; d_conics[3 * i + 2] = r1.x;
     d_opac[i] = r1.y;
     d_colors[3 * i] = r1.z; d_colors[3 * i + 1] = r1.w; d_colors[3 * i + 2] = r8;
+}
+
+// packs the caller's four arrays into the ctx-owned record arrays and fills QuadArgs
+int fill_quad(QuadArgs &q, const BlendArgs &a, gs_ctx *ctx, int32_t N) {
+    const size_t n16 = ((size_t)(N > 0 ? N : 1) * sizeof(float4) + 255) & ~(size_t)255;
+    int rc = gs_buf_reserve(ctx, &ctx->packed, 3 * n16);
+    if (rc) return rc;
+    char *base = (char *)ctx->packed.p;
+    float4 *geo = (float4 *)base, *con = (float4 *)(base + n16), *rgb = (float4 *)(base + 2 * n16);
+    if (N > 0) {
+        gs_prof_scope prof_(ctx, GS_K_PACK);
+        hipLaunchKernelGGL(pack_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, a.centers, a.colors,
+                           a.opacities, a.conics, geo, con, rgb);
+    }
+    q.geo = geo; q.con = con; q.rgb = rgb; q.vals = a.vals; q.ranges = a.ranges;
+    q.bg[0] = a.bg[0]; q.bg[1] = a.bg[1]; q.bg[2] = a.bg[2];
+    q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
+    return GS_OK;
 }
 
 int fill_args(BlendArgs &a, gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
@@ -358,7 +719,12 @@ extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, co
     switch (ctx->ppt) {
         case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_FWD); hipLaunchKernelGGL(blend_fwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, image, n_contrib, t_final); } break;
         case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_FWD); hipLaunchKernelGGL(blend_fwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, image, n_contrib, t_final); } break;
-        default: { gs_prof_scope prof_(ctx, GS_K_BLEND_FWD); hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(tiles), dim3(64), 0, ctx->stream, a, image, n_contrib, t_final); } break;
+        default: {
+            QuadArgs q;
+            if ((rc = fill_quad(q, a, ctx, N))) return rc;
+            gs_prof_scope prof_(ctx, GS_K_BLEND_FWD);
+            hipLaunchKernelGGL(blend_fwd_quad_kernel, dim3(tiles), dim3(64), 0, ctx->stream, q, image, n_contrib, t_final);
+        } break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;
@@ -388,7 +754,12 @@ extern "C" int gs_blend_backward(gs_ctx *ctx, int32_t N, const float *centers, c
         switch (ctx->ppt) {
             case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
             case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
-            default: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<4>, dim3(tiles), dim3(64), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
+            default: {
+                QuadArgs q;
+                if ((rc = fill_quad(q, a, ctx, N))) return rc;
+                gs_prof_scope prof_(ctx, GS_K_BLEND_BWD);
+                hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(tiles), dim3(64), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
+            } break;
         }
         GS_HIP(hipGetLastError());
     }

@@ -29,7 +29,7 @@ int gs_set_error(int code, const char *fmt, ...);
 // per-kernel HIP-event timing (off by default; see gs_ctx_profile)
 enum gs_kernel_id {
     GS_K_PREPROCESS, GS_K_COUNT, GS_K_SCAN, GS_K_OFFSETS, GS_K_DUPLICATE, GS_K_SORT, GS_K_RANGES,
-    GS_K_BLEND_FWD, GS_K_BLEND_BWD, GS_K_UNPACK, GS_K_PARAM_BWD, GS_K_NUM
+    GS_K_BLEND_FWD, GS_K_BLEND_BWD, GS_K_UNPACK, GS_K_PARAM_BWD, GS_K_PACK, GS_K_NUM
 };
 
 struct gs_prof_span {

@@ -66,7 +66,7 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
 
 static const char *const k_kernel_names[GS_K_NUM] = {
     "preprocess", "bin_count", "bin_scan", "bin_offsets", "bin_duplicate", "bin_sort", "bin_ranges",
-    "blend_forward", "blend_backward", "grad_unpack", "param_backward"};
+    "blend_forward", "blend_backward", "grad_unpack", "param_backward", "blend_pack"};
 
 static hipEvent_t prof_event(gs_ctx *c) {
     if (!c->prof_free.empty()) {
