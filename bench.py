@@ -164,8 +164,10 @@ def main():
     P = W * H
     alg_bytes = {   # SURVEY.md 8(d) per-launch algorithmic bytes
         "preprocess": N * (236 + 56),
-        "bin_sort": 6 * D * 24 + 8 * D,
-        "bin_duplicate": N * 24 + D * 12,
+        # tile sort: 2 passes x D x (4 histogram read + 8 read + 8 write); depth sort likewise over N
+        "bin_sort": 2 * D * 20,
+        "bin_depth_sort": 2 * N * 20,
+        "bin_duplicate": N * 28 + D * 8,
         "blend_forward": d_star * 40 + P * 20,
         "blend_backward": d_star * 40 + P * 20 + d_star * 36,
         "param_backward": N * (236 + 36) + N * 236,

@@ -260,9 +260,11 @@ class TileBinning:
 
 
 def match_gaus_to_tiles(ctx, queue, program, tiles_touched, radiis, depths,
-                        result_size=[979, 546], tile_size=16):
+                        result_size=[979, 546], tile_size=16, *, want_keys=True):
     """rasterization.py:6-25 (+ the per-tile filter/sort of :66-71).  `radiis` is accepted for
-    signature compatibility; like the reference's kernel (quirk Q11) it does not affect the keys."""
+    signature compatibility; like the reference's kernel (quirk Q11) it does not affect the keys.
+    want_keys=False skips materialising the 64-bit (tile<<32|depth) keys (the blend kernels only
+    need the gaussian ids and the tile ranges)."""
     c = _ctx(ctx)
     c.sync_stream()
     dev = c.device
@@ -273,12 +275,12 @@ def match_gaus_to_tiles(ctx, queue, program, tiles_touched, radiis, depths,
     D = ctypes.c_int64(0)
     check(c.lib.gs_bin_count(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts, ctypes.byref(D)), "gs_bin_count")
     tiles = math.ceil(W / ts) * math.ceil(H / ts)
-    keys = torch.empty((max(D.value, 1),), dtype=torch.int64, device=dev)
+    keys = torch.empty((max(D.value, 1),), dtype=torch.int64, device=dev) if want_keys else None
     vals = torch.empty((max(D.value, 1),), dtype=torch.int32, device=dev)
     ranges = torch.empty((tiles, 2), dtype=torch.int32, device=dev)
     check(c.lib.gs_bin_fill(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts, D.value, _ptr(keys), _ptr(vals),
                             _ptr(ranges)), "gs_bin_fill")
-    return TileBinning(keys[:D.value], vals[:D.value], ranges, D.value, [W, H], ts)
+    return TileBinning(keys[:D.value] if want_keys else None, vals[:D.value], ranges, D.value, [W, H], ts)
 
 
 def _binning_from_lists(mapped_keys, result_size, tile_size, device):

@@ -29,7 +29,7 @@ int gs_set_error(int code, const char *fmt, ...);
 // per-kernel HIP-event timing (off by default; see gs_ctx_profile)
 enum gs_kernel_id {
     GS_K_PREPROCESS, GS_K_COUNT, GS_K_SCAN, GS_K_OFFSETS, GS_K_DUPLICATE, GS_K_SORT, GS_K_RANGES,
-    GS_K_BLEND_FWD, GS_K_BLEND_BWD, GS_K_UNPACK, GS_K_PARAM_BWD, GS_K_PACK, GS_K_NUM
+    GS_K_BLEND_FWD, GS_K_BLEND_BWD, GS_K_UNPACK, GS_K_PARAM_BWD, GS_K_PACK, GS_K_DEPTH_SORT, GS_K_NUM
 };
 
 struct gs_prof_span {
@@ -47,17 +47,19 @@ struct gs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // binning workspace
-    gs_buf offsets;      // u32[N]     exclusive scan of tiles-per-gaussian
+    gs_buf counts;       // u32[N]     tiles per gaussian
+    gs_buf offsets;      // u32[N]     exclusive scan of tiles-per-gaussian in depth order
     gs_buf block_sums;   // u32[nblocks]
-    gs_buf total;        // u64[1]     D on device
-    gs_buf keys_tmp;     // u64[D]     unsorted keys
+    gs_buf total;        // u64 D, u32 max depth on device
+    gs_buf depth_sort;   // 2 x u32[N] keys + 2 x i32[N] values (ping-pong of the depth sort)
+    gs_buf keys_tmp;     // 2 x u32[D] tile ids (ping-pong of the tile sort)
     gs_buf vals_tmp;     // i32[D]
-    gs_buf sort_tmp;     // radix sort temporary storage
+    gs_buf radix_table;  // u32[256] digit totals + u32[256][blocks] per-block digit counts
     // blend workspace
     gs_buf packed;       // float4[3][N] packed per-gaussian blend attributes
     gs_buf grad_rows;    // float[N][16] 64-byte gradient rows for blend backward
     gs_buf tile_scratch; // rasterize_tile shim staging
-    uint64_t *total_host = nullptr;   // pinned
+    uint64_t *total_host = nullptr;   // pinned, 2 words
     // state carried from gs_bin_count to gs_bin_fill
     bool prof_on = false;
     std::vector<gs_prof_span> prof_spans;     // recorded, not yet read
@@ -65,6 +67,7 @@ struct gs_ctx {
     int ppt = 4;         // pixels per thread of the blend kernels (1, 2 or 4)
     int32_t bin_N = -1;
     int64_t bin_D = -1;
+    uint32_t bin_max_depth = 0;
 };
 
 int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);

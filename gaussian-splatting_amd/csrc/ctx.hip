@@ -41,7 +41,7 @@ extern "C" int gs_ctx_create(int device, void *stream, gs_ctx **out) {
     gs_ctx *c = new gs_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;
-    hipError_t e = hipHostMalloc((void **)&c->total_host, sizeof(uint64_t), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void **)&c->total_host, 2 * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         delete c;
         return gs_set_error(GS_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
@@ -66,7 +66,7 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
 
 static const char *const k_kernel_names[GS_K_NUM] = {
     "preprocess", "bin_count", "bin_scan", "bin_offsets", "bin_duplicate", "bin_sort", "bin_ranges",
-    "blend_forward", "blend_backward", "grad_unpack", "param_backward", "blend_pack"};
+    "blend_forward", "blend_backward", "grad_unpack", "param_backward", "blend_pack", "bin_depth_sort"};
 
 static hipEvent_t prof_event(gs_ctx *c) {
     if (!c->prof_free.empty()) {
@@ -132,8 +132,9 @@ extern "C" int gs_ctx_destroy(gs_ctx *ctx) {
     if (!ctx) return GS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    gs_buf *bufs[] = {&ctx->offsets, &ctx->block_sums, &ctx->total, &ctx->keys_tmp, &ctx->vals_tmp,
-                      &ctx->sort_tmp, &ctx->packed, &ctx->grad_rows, &ctx->tile_scratch};
+    gs_buf *bufs[] = {&ctx->counts, &ctx->offsets, &ctx->block_sums, &ctx->total, &ctx->depth_sort,
+                      &ctx->keys_tmp, &ctx->vals_tmp, &ctx->radix_table, &ctx->packed, &ctx->grad_rows,
+                      &ctx->tile_scratch};
     for (gs_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (gs_prof_span &sp : ctx->prof_spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }

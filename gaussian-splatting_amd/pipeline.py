@@ -60,7 +60,7 @@ class SplatPipeline:
         self.stats = {}
 
     # ---- forward ------------------------------------------------------------------------
-    def forward(self, view):
+    def forward(self, view, want_keys=False):
         c = self.ctx
         c.sync_stream()
         dev, N, f32, i32 = c.device, self.N, torch.float32, torch.int32
@@ -80,7 +80,8 @@ class SplatPipeline:
                                   api._ptr(depths), api._ptr(colors), api._ptr(conics), api._ptr(clamped),
                                   api._ptr(rect), api._ptr(radii), null, null, null, null, null, null),
               "gs_preprocess")
-        binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size, self.tile_size)
+        binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size, self.tile_size,
+                                          want_keys=want_keys)
         opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
         image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
                                                       self.pixel_offset)

@@ -73,9 +73,11 @@ int gs_preprocess(gs_ctx *ctx, int32_t N, const float *means, const float *log_s
 /* Replaces match_gaus_to_tiles (rasterization.py:6-25) + kernel tile_match (setup_gpu.py:23-44)
  * + the per-tile filter and RadixSort (rasterization.py:57,66-71), in O(D) instead of
  * O(tiles*N).  Two phases so the caller owns the D-sized outputs:
- *   gs_bin_count: tiles-per-gaussian + exclusive scan; returns D (host int64; one stream sync).
- *   gs_bin_fill : duplicate into key=(tile_id<<32)|u32(depth), val=gaussian; stable radix sort;
- *                 ranges[tile] = [start,end).  tile_id = tx*tiles_y + ty.
+ *   gs_bin_count: tiles-per-gaussian; returns D = their sum (host int64; one stream sync).
+ *   gs_bin_fill : stable radix sort of the gaussians by u32(depth), duplication in that order
+ *                 into (tile_id, gaussian) pairs, stable radix sort by tile_id;
+ *                 vals[D] = gaussian ids, ranges[tile] = [start,end), tile_id = tx*tiles_y + ty;
+ *                 keys[D] = (tile_id<<32)|u32(depth) of each entry, or NULL when not wanted.
  * Per tile the order is (depth asc, gaussian asc) = the reference's stable low-32-bit sort of
  * (g<<32)+depth; entries with u32(depth)==0 are dropped (rasterization.py:67).
  * gs_bin_fill must follow gs_bin_count on the same ctx with the same inputs. */

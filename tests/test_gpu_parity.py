@@ -316,7 +316,7 @@ def test_full_size_properties(gpu_ctx):
     import gsplat_amd as gs
     cam, R, t, g, rs = synth_scene(1_000_000, 1920, 1080)
     pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
-    image, st = pipe.forward(gs.View(cam, R, t))
+    image, st = pipe.forward(gs.View(cam, R, t), want_keys=True)
     b = st["binning"]
     keys = b.keys.cpu().numpy().view(np.uint64)
     ranges = b.ranges.cpu().numpy()

@@ -1,0 +1,20 @@
+"""Run a few forward+backward views of the bench scene (for rocprofv3 --pmc passes)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gsplat_amd as gs
+from bench import make_scene, make_views
+
+N = int(os.environ.get("GS_N", 1_000_000))
+W, H = 1920, 1080
+g, cam = make_scene(N, W, H, (1.0, 3.0))
+ctx, _, _ = gs.setup_gpu(0)
+pipe = gs.SplatPipeline(g, [W, H], ctx=ctx)
+views = make_views(gs, cam, 8)
+grads = gs.FlatGrads(N, ctx.device)
+target = torch.rand(W, H, 3, device=ctx.device)
+for v in range(int(os.environ.get("GS_VIEWS", 2))):
+    image, st = pipe.forward(views[v])
+    pipe.backward(st, (image - target) * 1e-6, grads)
+torch.cuda.synchronize()
+print("done", st["binning"].D)
