@@ -155,6 +155,26 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+__device__ __forceinline__ float row_sum_to_lane15(float v) {   // lane 15 of every 16-lane row
+    v += dpp_term<0x111, 0xF>(v);
+    v += dpp_term<0x112, 0xF>(v);
+    v += dpp_term<0x114, 0xF>(v);
+    v += dpp_term<0x118, 0xF>(v);
+    return v;
+}
+// v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b; v_permlane16_swap: odd 16-lane rows of a
+// <-> even rows of b.  a + b afterwards holds a's partner sums in one half and b's in the other.
+__device__ __forceinline__ void swap32(float &a, float &b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float &a, float &b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
 constexpr int GRAD_ROW = 16;   // floats per gaussian in the 64-byte gradient rows
 // row layout: 0,1 d/dcenter  2,3,4 d/dconic  5 d/dopacity  6,7,8 d/dcolor
 
@@ -329,7 +349,7 @@ struct QuadArgs {
     const int32_t *vals;
     const int2 *ranges;
     float bg[3];
-    int W, H, tiles_y;
+    int W, H, tiles_y, ntiles;
     float pixel_offset;
 };
 
@@ -375,17 +395,33 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 geo, const floa
     return !(-qmin * 0.999f + 1e-4f < geo.w);
 }
 
-__global__ __launch_bounds__(64) void blend_fwd_quad_kernel(QuadArgs a, float *__restrict__ image,
-                                                            int32_t *__restrict__ n_contrib,
-                                                            float *__restrict__ t_final) {
-    __shared__ float4 s_geo[64];
-    __shared__ float4 s_con[64];
-    __shared__ float4 s_rgb[64];
-    __shared__ int s_idx[64];
+// Four tiles per 256-thread workgroup, one wave64 each, with wave-private LDS and no workgroup
+// barrier: a CU holds at most 16 workgroups, so single-wave workgroups would cap occupancy at 4 waves
+// per SIMD; four independent waves per workgroup reach 8.  LDS operations of one wave execute in
+// order, so a wave-level fence is all that staging -> broadcast reads needs.
+constexpr int QUAD_WAVES = 4;
 
-    const int tile = blockIdx.x;
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
+__global__ __launch_bounds__(64 * QUAD_WAVES) void blend_fwd_quad_kernel(QuadArgs a, float *__restrict__ image,
+                                                                         int32_t *__restrict__ n_contrib,
+                                                                         float *__restrict__ t_final) {
+    __shared__ float4 s_geo_[QUAD_WAVES][64];
+    __shared__ float4 s_con_[QUAD_WAVES][64];   // .w = original list index (bits)
+    __shared__ float4 s_rgb_[QUAD_WAVES][64];
+
+    const int wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * QUAD_WAVES + wv;
+    if (tile >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
+    float4 *s_geo = s_geo_[wv], *s_con = s_con_[wv], *s_rgb = s_rgb_[wv];
     const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int qy = lane & 7, qx = lane >> 3;
     const int X0 = tx * TILE, Y0 = ty * TILE;
     const float off = a.pixel_offset;
@@ -409,8 +445,8 @@ __global__ __launch_bounds__(64) void blend_fwd_quad_kernel(QuadArgs a, float *_
     }
 
     for (int base = 0; base < len; base += 64) {
-        if (__all(done[0] && done[1] && done[2] && done[3])) break;
-        __syncthreads();
+        if (wave_all(done[0] && done[1] && done[2] && done[3])) break;
+        wave_lds_fence();                    // the previous batch's reads are complete
         const int i = base + lane;
         bool keep = false;
         float4 geo, con;
@@ -425,12 +461,12 @@ __global__ __launch_bounds__(64) void blend_fwd_quad_kernel(QuadArgs a, float *_
         const int n = __popcll(m);
         if (keep) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
+            con.w = __int_as_float(i);
             s_geo[pos] = geo;
             s_con[pos] = con;
             s_rgb[pos] = a.rgb[g];
-            s_idx[pos] = i;
         }
-        __syncthreads();
+        wave_lds_fence();
 
         for (int j = 0; j < n; j++) {
             const float4 ge = s_geo[j];
@@ -446,21 +482,21 @@ __global__ __launch_bounds__(64) void blend_fwd_quad_kernel(QuadArgs a, float *_
             bool cand[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) cand[k] = !done[k] && p[k] > ge.w;
-            if (!__any(cand[0] || cand[1] || cand[2] || cand[3])) continue;
+            if (!wave_any(cand[0] || cand[1] || cand[2] || cand[3])) continue;
             const float4 rgb = s_rgb[j];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (!__any(cand[k])) continue;
+                if (!wave_any(cand[k])) continue;
                 const float G = __builtin_amdgcn_exp2f(p[k]);
                 const float alpha = fminf(ALPHA_MAX, ge.z * G);
                 const bool valid = cand[k] && !(p[k] > 0.0f) && !(alpha < ALPHA_MIN);
                 float w = valid ? alpha * T[k] : 0.0f;
                 float tT = T[k] - w;
                 const bool brk = tT < T_MIN;
-                if (__any(brk)) {   // rare: at most once per pixel
+                if (wave_any(brk)) {   // rare: at most once per pixel
                     w = brk ? 0.0f : w;
                     tT = brk ? T[k] : tT;
-                    last[k] = brk ? s_idx[j] + 1 : last[k];
+                    last[k] = brk ? __float_as_int(co.w) + 1 : last[k];
                     done[k] = done[k] || brk;
                     broke[k] = broke[k] || brk;
                 }
@@ -492,20 +528,23 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void blend_bwd_quad_kernel(QuadArgs a, const int32_t *__restrict__ n_contrib,
-                                                            const float *__restrict__ t_final,
-                                                            const float *__restrict__ dL_dimage,
-                                                            float *__restrict__ grad_rows) {
-    __shared__ float4 s_geo[64];
-    __shared__ float4 s_con[64];
-    __shared__ float4 s_rgb[64];
-    __shared__ int s_idx[64];
-    __shared__ int s_g[64];
-    __shared__ __align__(16) float s_grad[64][12];
+__global__ __launch_bounds__(64 * QUAD_WAVES) void blend_bwd_quad_kernel(QuadArgs a,
+                                                                         const int32_t *__restrict__ n_contrib,
+                                                                         const float *__restrict__ t_final,
+                                                                         const float *__restrict__ dL_dimage,
+                                                                         float *__restrict__ grad_rows) {
+    // per wave: 64 staged records of 12 words (geo | con | rgb).  Once entry j has been processed
+    // its record is dead, so lane 63 parks the 9 reduced gradients in place: geo.xyzw, con.xyzw,
+    // rgb.x; rgb.w keeps the gaussian id for the flush.
+    __shared__ float4 s_rec_[QUAD_WAVES][3][64];
 
-    const int tile = blockIdx.x;
+    const int wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * QUAD_WAVES + wv;
+    if (tile >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
+    float4 *s_geo = s_rec_[wv][0], *s_con = s_rec_[wv][1], *s_rgb = s_rec_[wv][2];
+    const float *s_flat = reinterpret_cast<const float *>(s_rec_[wv]);
     const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int qy = lane & 7, qx = lane >> 3;
     const int X0 = tx * TILE, Y0 = ty * TILE;
     const float off = a.pixel_offset;
@@ -513,6 +552,12 @@ __global__ __launch_bounds__(64) void blend_bwd_quad_kernel(QuadArgs a, const in
     const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
     const float xlo = (float)X0 - off, xhi = xlo + 15.0f, ylo = (float)Y0 - off, yhi = ylo + 15.0f;
     const int2 rg = a.ranges[tile];
+
+    // lane 15 of row r finishes gradient words r and 4+r; the factors undo the log2 pre-scaling
+    // (d power/d(.) = ln2 * d power2/d(.)) and map (a',b',c') back to the conic (A,B,C)
+    const int row = lane >> 4;
+    const float sc0 = row < 2 ? LN2 : (row == 2 ? -0.5f : -1.0f);
+    const float sc1 = row == 0 ? -0.5f : 1.0f;
 
     // per pixel: transmittance T (walked backwards by division), dL/dpixel, and the running
     // scalar s = T_final*(bg.dL) + sum_{k behind} w_k (c_k.dL)  (what sits behind the current
@@ -545,7 +590,7 @@ __global__ __launch_bounds__(64) void blend_bwd_quad_kernel(QuadArgs a, const in
     const int nbatch = (max_end + 63) / 64;
     for (int b = nbatch - 1; b >= 0; b--) {
         const int base = b * 64;
-        __syncthreads();
+        wave_lds_fence();                    // the previous batch's flush reads are complete
         const int i = base + lane;
         bool keep = false;
         float4 geo, con;
@@ -560,19 +605,20 @@ __global__ __launch_bounds__(64) void blend_bwd_quad_kernel(QuadArgs a, const in
         const int n = __popcll(m);
         if (keep) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
+            float4 rgb = a.rgb[g];
+            con.w = __int_as_float(i);
+            rgb.w = __int_as_float(g);
             s_geo[pos] = geo;
             s_con[pos] = con;
-            s_rgb[pos] = a.rgb[g];
-            s_idx[pos] = i;
-            s_g[pos] = g;
+            s_rgb[pos] = rgb;
         }
-        __syncthreads();
+        wave_lds_fence();
 
         unsigned long long touched = 0ull;   // wave-uniform: entries that received a gradient
         for (int j = n - 1; j >= 0; j--) {
             const float4 ge = s_geo[j];
             const float4 co = s_con[j];
-            const int idx = s_idx[j];
+            const int idx = __float_as_int(co.w);
             const float dx0 = ge.x - fx0, dx1 = ge.x - fx1, dy0 = ge.y - fy0, dy1 = ge.y - fy1;
             const float adx0 = co.x * dx0, adx1 = co.x * dx1;
             const float cdy0 = co.z * dy0, cdy1 = co.z * dy1;
@@ -589,20 +635,20 @@ __global__ __launch_bounds__(64) void blend_bwd_quad_kernel(QuadArgs a, const in
             bool cand[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) cand[k] = idx < end_k[k] && p[k] > ge.w;
-            if (!__any(cand[0] || cand[1] || cand[2] || cand[3])) continue;
+            if (!wave_any(cand[0] || cand[1] || cand[2] || cand[3])) continue;
             const float4 rgb = s_rgb[j];
             float g_cx = 0.f, g_cy = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
             bool any_valid = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (!__any(cand[k])) continue;
+                if (!wave_any(cand[k])) continue;
                 const float dx = (k >> 1) ? dx1 : dx0, dy = (k & 1) ? dy1 : dy0;
                 const float adx = (k >> 1) ? adx1 : adx0, cdy = (k & 1) ? cdy1 : cdy0;
                 const float G = __builtin_amdgcn_exp2f(p[k]);
                 const float araw = ge.z * G;
                 const float alpha = fminf(ALPHA_MAX, araw);
                 const bool valid = cand[k] && !(p[k] > 0.0f) && !(alpha < ALPHA_MIN);
-                if (!__any(valid)) continue;
+                if (!wave_any(valid)) continue;
                 any_valid = true;
                 const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
                 const float Tn = T[k] * inv;              // transmittance in front of this gaussian
@@ -625,26 +671,34 @@ __global__ __launch_bounds__(64) void blend_bwd_quad_kernel(QuadArgs a, const in
                 g_C = __builtin_fmaf(q, dy * dy, g_C);
             }
             if (!any_valid) continue;    // wave-uniform
-            g_cx = wave_sum_to_lane63(g_cx); g_cy = wave_sum_to_lane63(g_cy);
-            g_A = wave_sum_to_lane63(g_A); g_B = wave_sum_to_lane63(g_B); g_C = wave_sum_to_lane63(g_C);
-            g_o = wave_sum_to_lane63(g_o);
-            g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+            // 9 wave-wide sums in 6 lane swaps + 6 adds + 14 DPP adds instead of 54 DPP adds (a DPP add
+            // issues in 4 cycles, twice a plain VALU op): permlane32/16 swaps fold two values per
+            // instruction, leaving each 16-lane row with its own pair of values to finish.
+            swap32(g_cx, g_A); const float w0 = g_cx + g_A;
+            swap32(g_cy, g_B); const float w1 = g_cy + g_B;
+            swap32(g_C, g_r);  const float w2 = g_C + g_r;
+            swap32(g_o, g_g);  const float w3 = g_o + g_g;
+            float u0 = w0, u1 = w1, u2 = w2, u3 = w3;
+            swap16(u0, u1); const float x0 = row_sum_to_lane15(u0 + u1);   // rows: d cx, d cy, d a', d b'
+            swap16(u2, u3); const float x1 = row_sum_to_lane15(u2 + u3);   // rows: d c', d o, d r, d g
+            g_b = wave_sum_to_lane63(g_b);
             touched |= 1ull << j;
-            if (lane == 63) {
-                // undo the log2 pre-scaling: d power/d(.) = ln2 * d power2/d(.)
-                *reinterpret_cast<float4 *>(&s_grad[j][0]) = make_float4(LN2 * g_cx, LN2 * g_cy, -0.5f * g_A, -g_B);
-                *reinterpret_cast<float4 *>(&s_grad[j][4]) = make_float4(-0.5f * g_C, g_o, g_r, g_g);
-                s_grad[j][8] = g_b;
+            if ((lane & 15) == 15) {
+                reinterpret_cast<float *>(&s_geo[j])[lane >> 4] = x0 * sc0;
+                reinterpret_cast<float *>(&s_con[j])[lane >> 4] = x1 * sc1;
             }
+            if (lane == 63) s_rgb[j].x = g_b;
         }
-        __syncthreads();
+        wave_lds_fence();
         // flush: one 64-byte row per gaussian, 4 rows per wave-instruction, lanes 0..8 of each
         // 16-lane group active -> one memory-side atomic request per (tile, gaussian)
         const int comp = lane & 15;
         for (int e0 = 0; e0 < n; e0 += 4) {
             const int e = e0 + (lane >> 4);
-            if (e < n && comp < 9 && ((touched >> e) & 1ull))
-                atomicAdd(&grad_rows[(size_t)s_g[e] * GRAD_ROW + comp], s_grad[e][comp]);
+            if (e < n && comp < 9 && ((touched >> e) & 1ull)) {
+                const int gid = __float_as_int(s_rgb[e].w);
+                atomicAdd(&grad_rows[(size_t)gid * GRAD_ROW + comp], s_flat[(comp >> 2) * 256 + e * 4 + (comp & 3)]);
+            }
         }
     }
 }
@@ -679,6 +733,7 @@ int fill_quad(QuadArgs &q, const BlendArgs &a, gs_ctx *ctx, int32_t N) {
     q.geo = geo; q.con = con; q.rgb = rgb; q.vals = a.vals; q.ranges = a.ranges;
     q.bg[0] = a.bg[0]; q.bg[1] = a.bg[1]; q.bg[2] = a.bg[2];
     q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
+    q.ntiles = gs_div_up(a.W, TILE) * a.tiles_y;
     return GS_OK;
 }
 
@@ -723,7 +778,7 @@ extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, co
             QuadArgs q;
             if ((rc = fill_quad(q, a, ctx, N))) return rc;
             gs_prof_scope prof_(ctx, GS_K_BLEND_FWD);
-            hipLaunchKernelGGL(blend_fwd_quad_kernel, dim3(tiles), dim3(64), 0, ctx->stream, q, image, n_contrib, t_final);
+            hipLaunchKernelGGL(blend_fwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, image, n_contrib, t_final);
         } break;
     }
     GS_HIP(hipGetLastError());
@@ -758,7 +813,7 @@ extern "C" int gs_blend_backward(gs_ctx *ctx, int32_t N, const float *centers, c
                 QuadArgs q;
                 if ((rc = fill_quad(q, a, ctx, N))) return rc;
                 gs_prof_scope prof_(ctx, GS_K_BLEND_BWD);
-                hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(tiles), dim3(64), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
+                hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
             } break;
         }
         GS_HIP(hipGetLastError());
