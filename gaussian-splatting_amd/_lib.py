@@ -15,6 +15,11 @@ class GsCamera(ctypes.Structure):
                 ("tile_size", ctypes.c_int32), ("sh_degree", ctypes.c_int32)]
 
 
+class GsViewBackward(ctypes.Structure):
+    _fields_ = [("cam", ctypes.POINTER(GsCamera)), ("radii", ctypes.c_void_p), ("clamped", ctypes.c_void_p),
+                ("grad_rows", ctypes.c_void_p)]
+
+
 class GsError(RuntimeError):
     pass
 
@@ -45,6 +50,10 @@ SIGNATURES = {
                                          _I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_backward_params": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, ctypes.POINTER(GsCamera), _P, _P, _P,
                                           _P, _P, _I32, _P, _P, _P, _P]),
+    "gs_blend_backward_rows": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),
+                                              _I32, _I32, _I32, _F, _P, _P, _P, _P]),
+    "gs_backward_params_batch": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, _I32,
+                                                ctypes.POINTER(GsViewBackward), _I32, _P, _P, _P, _P, _P]),
     "rasterize_tile": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
 }

@@ -785,6 +785,30 @@ extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, co
     return GS_OK;
 }
 
+namespace {
+
+// launches K7 into `rows` ([N][16], zeroed here)
+int blend_backward_into_rows(gs_ctx *ctx, const BlendArgs &a, int32_t N, int64_t D, int tiles,
+                             const int32_t *n_contrib, const float *t_final, const float *dL_dimage, float *rows) {
+    int rc;
+    GS_HIP(hipMemsetAsync(rows, 0, (size_t)N * GRAD_ROW * sizeof(float), ctx->stream));
+    if (D <= 0) return GS_OK;
+    switch (ctx->ppt) {
+        case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
+        case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
+        default: {
+            QuadArgs q;
+            if ((rc = fill_quad(q, a, ctx, N))) return rc;
+            gs_prof_scope prof_(ctx, GS_K_BLEND_BWD);
+            hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
+        } break;
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace
+
 extern "C" int gs_blend_backward(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
                                  const float *opacities, const float *conics, const int32_t *vals,
                                  const int32_t *ranges, int64_t D, const float *background_host3,
@@ -803,23 +827,28 @@ extern "C" int gs_blend_backward(gs_ctx *ctx, int32_t N, const float *centers, c
     GS_HIP(hipSetDevice(ctx->device));
     if ((rc = gs_buf_reserve(ctx, &ctx->grad_rows, (size_t)N * GRAD_ROW * sizeof(float)))) return rc;
     float *rows = (float *)ctx->grad_rows.p;
-    GS_HIP(hipMemsetAsync(rows, 0, (size_t)N * GRAD_ROW * sizeof(float), ctx->stream));
     const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
-    if (D > 0) {
-        switch (ctx->ppt) {
-            case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
-            case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
-            default: {
-                QuadArgs q;
-                if ((rc = fill_quad(q, a, ctx, N))) return rc;
-                gs_prof_scope prof_(ctx, GS_K_BLEND_BWD);
-                hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
-            } break;
-        }
-        GS_HIP(hipGetLastError());
-    }
+    if ((rc = blend_backward_into_rows(ctx, a, N, D, tiles, n_contrib, t_final, dL_dimage, rows))) return rc;
     { gs_prof_scope prof_(ctx, GS_K_UNPACK); hipLaunchKernelGGL(unpack_rows_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, rows,
                        dL_dcenters, dL_dconics, dL_dopacities, dL_dcolors); }
     GS_HIP(hipGetLastError());
     return GS_OK;
+}
+
+extern "C" int gs_blend_backward_rows(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                                      const float *opacities, const float *conics, const int32_t *vals,
+                                      const int32_t *ranges, int64_t D, const float *background_host3,
+                                      int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                                      const int32_t *n_contrib, const float *t_final, const float *dL_dimage,
+                                      float *grad_rows) {
+    BlendArgs a;
+    int rc = fill_args(a, ctx, N, centers, colors, opacities, conics, vals, ranges, D, background_host3,
+                       res_w, res_h, tile_size, pixel_offset);
+    if (rc) return rc;
+    GS_REQUIRE(n_contrib && t_final && dL_dimage, "gs_blend_backward_rows: NULL forward state / dL_dimage");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(grad_rows && ((uintptr_t)grad_rows & 63) == 0, "gs_blend_backward_rows: grad_rows must be non-NULL and 64-byte aligned");
+    GS_HIP(hipSetDevice(ctx->device));
+    const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
+    return blend_backward_into_rows(ctx, a, N, D, tiles, n_contrib, t_final, dL_dimage, grad_rows);
 }

@@ -6,55 +6,104 @@
 // The reference's versions are undefined at HEAD (defects B3, B9, B10, B13), so this kernel
 // implements the evident intent: the exact derivative of the LIVE forward path
 // (forward_pass.py:56-127 with quirks Q1-Q5) w.r.t. the stored parameters, pinned by fp64 autograd
-// of the oracle restatement.  One thread per gaussian; HBM-bound (236 B parameters + 36 B incoming
-// gradients in, 236 B out), so the forward intermediates (R, M, Sigma, W rows, cov2d) are
-// recomputed in fp64 from the parameters rather than re-read (132 B of extras in the reference).
+// of the oracle restatement.  One thread per gaussian; the forward intermediates (R, M, Sigma, W
+// rows, cov2d) are recomputed in fp64 from the parameters rather than re-read (132 B of extras in
+// the reference).
+//
+// Multi-view batches (the reference trains one view per iteration, train.py:18-43): one launch
+// takes up to 8 views.  R, M and Sigma do not depend on the view, dL/dSigma is linear, so the
+// thread reads its 236 B of parameters once, loops over the views accumulating dL/dmean, dL/dSigma
+// and dL/dSH in registers, runs the Sigma -> (scale, quaternion) chain once and writes its 236 B
+// of gradients once: 236 + 8*(64+7) + 236 B per gaussian instead of 8 * (236 + 36 + 2*236) with
+// one accumulate-launch per view.
 #include "common.h"
 #include "precam.h"
 #include <math.h>
+#include <string.h>
 
 namespace {
 
+constexpr int MAX_BATCH_VIEWS = 8;
+
+struct ViewIn {
+    PreCam cam;
+    const int32_t *radii;
+    const uint8_t *clamped;
+    const float *rows;        // ROWS: [N][16] blend-backward rows (d centre 2, d conic 3, d opacity, d colour 3)
+    const float *d_centers;   // !ROWS: the reference-shaped separate arrays
+    const float *d_conics;
+    const float *d_colors;
+};
+
+struct BatchArgs {
+    ViewIn v[MAX_BATCH_VIEWS];
+    int n_views;
+};
+
+template <bool ROWS>
 __global__ __launch_bounds__(256) void param_bwd_kernel(
     int N, const float *__restrict__ means, const float *__restrict__ log_scales,
-    const float *__restrict__ quats, const float *__restrict__ sh, PreCam cam,
-    const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
-    const float *__restrict__ dL_dcenters, const float *__restrict__ dL_dconics,
-    const float *__restrict__ dL_dcolors, int accumulate, float *__restrict__ dL_dmeans,
-    float *__restrict__ dL_dlog_scales, float *__restrict__ dL_dquats, float *__restrict__ dL_dsh) {
+    const float *__restrict__ quats, const float *__restrict__ sh, const float *__restrict__ opacity,
+    int opacity_is_logit, const BatchArgs args, int accumulate, float *__restrict__ dL_dmeans,
+    float *__restrict__ dL_dlog_scales, float *__restrict__ dL_dquats, float *__restrict__ dL_dopacity,
+    float *__restrict__ dL_dsh) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
 
     double g_mean[3] = {0, 0, 0}, g_ls[3] = {0, 0, 0}, g_q[4] = {0, 0, 0, 0};
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // sum over views of G + G^T, G = dL/dSigma
+    float g_op = 0.0f;
+    float acc_sh[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) acc_sh[k] = 0.0f;
     float4 *out_sh = reinterpret_cast<float4 *>(dL_dsh + (size_t)i * 48);
-    const bool visible = radii[i] > 0;
+    bool any = false;
 
-    if (visible) {
-        const double x = means[3 * i], y = means[3 * i + 1], z = means[3 * i + 2];
+    const double x = means[3 * i], y = means[3 * i + 1], z = means[3 * i + 2];
+    const double qw = quats[4 * i], qx = quats[4 * i + 1], qy = quats[4 * i + 2], qz = quats[4 * i + 3];
+    const double n2 = qw * qw + qx * qx + qy * qy + qz * qz;
+    const double s = 2.0 / n2;
+    const double Q[9] = {-(qy * qy + qz * qz), qx * qy - qz * qw, qx * qz + qy * qw,
+                         qx * qy + qz * qw, -(qx * qx + qz * qz), qy * qz - qx * qw,
+                         qx * qz - qy * qw, qy * qz + qx * qw, -(qx * qx + qy * qy)};
+    double R[9];
+    for (int k = 0; k < 9; k++) R[k] = s * Q[k];
+    R[0] += 1.0; R[4] += 1.0; R[8] += 1.0;
+    const double sc[3] = {exp((double)log_scales[3 * i]), exp((double)log_scales[3 * i + 1]),
+                          exp((double)log_scales[3 * i + 2])};
+
+#pragma unroll 1
+    for (int v = 0; v < args.n_views; v++) {
+        const ViewIn &V = args.v[v];
+        const PreCam &cam = V.cam;
+        if (V.radii[i] <= 0) continue;
+        any = true;
+
+        float in_c[2], in_con[3], in_col[3];
+        if (ROWS) {
+            const float4 *r = reinterpret_cast<const float4 *>(V.rows + (size_t)i * 16);
+            const float4 r0 = r[0], r1 = r[1];
+            in_c[0] = r0.x; in_c[1] = r0.y;
+            in_con[0] = r0.z; in_con[1] = r0.w; in_con[2] = r1.x;
+            g_op += r1.y;
+            in_col[0] = r1.z; in_col[1] = r1.w; in_col[2] = V.rows[(size_t)i * 16 + 8];
+        } else {
+            in_c[0] = V.d_centers[2 * i]; in_c[1] = V.d_centers[2 * i + 1];
+            for (int k = 0; k < 3; k++) { in_con[k] = V.d_conics[3 * i + k]; in_col[k] = V.d_colors[3 * i + k]; }
+        }
 
         // ---- 2D centre <- world mean (quirk Q1: proj_mat on world coordinates)
         {
-            const double dcx = dL_dcenters[2 * i], dcy = dL_dcenters[2 * i + 1];
+            const double dcx = in_c[0], dcy = in_c[1];
             const double mw = 1.0 / (z + .00000001);
             g_mean[0] += dcx * (.5 * cam.W * cam.p00 * mw);
             g_mean[1] += dcy * (.5 * cam.H * cam.p11 * mw);
             g_mean[2] += -dcx * (.5 * cam.W * cam.p00 * x * mw * mw) - dcy * (.5 * cam.H * cam.p11 * y * mw * mw);
         }
 
-        // ---- recompute R, S', M, Sigma, W rows, cov2d (forward_pass.py:74-86)
+        // ---- recompute S', M, Sigma, W rows, cov2d (forward_pass.py:74-86)
         const double tz = cam.Rt[6] * x + cam.Rt[7] * y + cam.Rt[8] * z + cam.t[2];
-        const double qw = quats[4 * i], qx = quats[4 * i + 1], qy = quats[4 * i + 2], qz = quats[4 * i + 3];
-        const double n2 = qw * qw + qx * qx + qy * qy + qz * qz;
-        const double s = 2.0 / n2;
-        const double Q[9] = {-(qy * qy + qz * qz), qx * qy - qz * qw, qx * qz + qy * qw,
-                             qx * qy + qz * qw, -(qx * qx + qz * qz), qy * qz - qx * qw,
-                             qx * qz - qy * qw, qy * qz + qx * qw, -(qx * qx + qy * qy)};
-        double R[9];
-        for (int k = 0; k < 9; k++) R[k] = s * Q[k];
-        R[0] += 1.0; R[4] += 1.0; R[8] += 1.0;
         const double sm = cam.scale_mod;
-        const double sc[3] = {exp((double)log_scales[3 * i]), exp((double)log_scales[3 * i + 1]),
-                              exp((double)log_scales[3 * i + 2])};
         const double S[9] = {sc[0] * sm, sm, sm, sm, sc[1] * sm, sm, sm, sm, sc[2] * sm};
         double M[9], Sg[9];
         for (int r = 0; r < 3; r++)
@@ -78,7 +127,7 @@ __global__ __launch_bounds__(256) void param_bwd_kernel(
         const double det = a * c - b * b;
 
         // ---- conic (A,B,C) = (c, -b, a)/det  ->  cov2d (a,b,c)
-        const double gA = dL_dconics[3 * i], gB = dL_dconics[3 * i + 1], gC = dL_dconics[3 * i + 2];
+        const double gA = in_con[0], gB = in_con[1], gC = in_con[2];
         const double inv2 = 1.0 / (det * det);
         const double d_a = (-c * c * gA + b * c * gB - b * b * gC) * inv2;
         const double d_b = (2.0 * b * c * gA - (det + 2.0 * b * b) * gB + 2.0 * a * b * gC) * inv2;
@@ -92,46 +141,13 @@ __global__ __launch_bounds__(256) void param_bwd_kernel(
             g_mean[2] += d_tz * cam.Rt[8];
         }
 
-        // ---- cov2d -> Sigma (G) -> M: dM = (G + G^T) M
-        double H[9];   // G + G^T
+        // ---- cov2d -> Sigma: G + G^T, summed over the views (Sigma does not depend on the view)
         for (int r = 0; r < 3; r++)
             for (int cc = 0; cc < 3; cc++) {
                 const double g_rc = d_a * W0[r] * W0[cc] + d_b * W0[r] * W1[cc] + d_c * W1[r] * W1[cc];
                 const double g_cr = d_a * W0[cc] * W0[r] + d_b * W0[cc] * W1[r] + d_c * W1[cc] * W1[r];
-                H[3 * r + cc] = g_rc + g_cr;
+                H[3 * r + cc] += g_rc + g_cr;
             }
-        double dM[9];
-        for (int r = 0; r < 3; r++)
-            for (int cc = 0; cc < 3; cc++)
-                dM[3 * r + cc] = H[3 * r] * M[cc] + H[3 * r + 1] * M[3 + cc] + H[3 * r + 2] * M[6 + cc];
-
-        // ---- M = R S': d(log scale_k) = (R^T dM)_kk * scale_mod * s_k
-        for (int k = 0; k < 3; k++) {
-            const double dS_kk = R[k] * dM[k] + R[3 + k] * dM[3 + k] + R[6 + k] * dM[6 + k];
-            g_ls[k] = dS_kk * sm * sc[k];
-        }
-        // dR = dM S'^T
-        double dR[9];
-        for (int r = 0; r < 3; r++)
-            for (int cc = 0; cc < 3; cc++)
-                dR[3 * r + cc] = dM[3 * r] * S[3 * cc] + dM[3 * r + 1] * S[3 * cc + 1] + dM[3 * r + 2] * S[3 * cc + 2];
-        // R = I + (2/n2) Q(q)  (normalise-then-divide-by-squared-norm is scale invariant)
-        {
-            double QD = 0.0;
-            for (int k = 0; k < 9; k++) QD += Q[k] * dR[k];
-            const double D00 = dR[0], D01 = dR[1], D02 = dR[2], D10 = dR[3], D11 = dR[4], D12 = dR[5],
-                         D20 = dR[6], D21 = dR[7], D22 = dR[8];
-            const double pw = -qz * D01 + qy * D02 + qz * D10 - qx * D12 - qy * D20 + qx * D21;
-            const double px = qy * D01 + qz * D02 + qy * D10 - 2 * qx * D11 - qw * D12 + qz * D20 + qw * D21 - 2 * qx * D22;
-            const double py = -2 * qy * D00 + qx * D01 + qw * D02 + qx * D10 + qz * D12 - qw * D20 + qz * D21 - 2 * qy * D22;
-            const double pz = -2 * qz * D00 - qw * D01 + qx * D02 + qw * D10 - 2 * qz * D11 + qy * D12 + qx * D20 + qy * D21;
-            const double k2 = 2.0 * s * QD / n2;   // (4 QD / n2^2)
-            g_q[0] = s * pw - k2 * qw;
-            g_q[1] = s * px - k2 * qx;
-            g_q[2] = s * py - k2 * qy;
-            g_q[3] = s * pz - k2 * qz;
-        }
-
         // ---- colour -> SH coefficients and view direction -> mean (py_compute_color)
         double vx = x - cam.cam_pos[0], vy = y - cam.cam_pos[1], vz = z - cam.cam_pos[2];
         const double vn = sqrt(vx * vx + vy * vy + vz * vz);
@@ -174,33 +190,21 @@ __global__ __launch_bounds__(256) void param_bwd_kernel(
         double ddx = 0, ddy = 0, ddz = 0;   // dL/d(dir)
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const double dcol = clamped[3 * i + ch] ? 0.0 : (double)dL_dcolors[3 * i + ch];
-            float o[16];
+            const double dcol = V.clamped[3 * i + ch] ? 0.0 : (double)in_col[ch];
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const float4 f = sh4[ch * 4 + v];
+            for (int vv = 0; vv < 4; vv++) {
+                const float4 f = sh4[ch * 4 + vv];
                 const float coef[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int k = 4 * v + e;
+                    const int k = 4 * vv + e;
                     if (k < nb) {
                         ddx += dcol * bx[k] * (double)coef[e];
                         ddy += dcol * by[k] * (double)coef[e];
                         ddz += dcol * bz[k] * (double)coef[e];
-                        o[k] = (float)(dcol * basis[k]);
-                    } else {
-                        o[k] = 0.0f;
+                        acc_sh[ch * 16 + k] += (float)(dcol * basis[k]);
                     }
                 }
-            }
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                float4 w = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
-                if (accumulate) {
-                    const float4 p = out_sh[ch * 4 + v];
-                    w.x += p.x; w.y += p.y; w.z += p.z; w.w += p.w;
-                }
-                out_sh[ch * 4 + v] = w;
             }
         }
         // dir = v/|v|: dL/dv = (dL/ddir - dir (dir . dL/ddir)) / |v|   (dnormvdv, setup_gpu.py:256-266)
@@ -208,21 +212,83 @@ __global__ __launch_bounds__(256) void param_bwd_kernel(
         g_mean[0] += (ddx - dx * dot) / vn;
         g_mean[1] += (ddy - dy * dot) / vn;
         g_mean[2] += (ddz - dz * dot) / vn;
-    } else if (!accumulate) {
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int v = 0; v < 12; v++) out_sh[v] = zero;
+    }
+
+    if (any) {
+        // ---- Sigma -> M: dM = (G + G^T) M, with any view's scale_mod (it is a frame constant)
+        const double sm = args.v[0].cam.scale_mod;
+        const double S[9] = {sc[0] * sm, sm, sm, sm, sc[1] * sm, sm, sm, sm, sc[2] * sm};
+        double M[9];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++)
+                M[3 * r + c] = R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c];
+        double dM[9];
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++)
+                dM[3 * r + cc] = H[3 * r] * M[cc] + H[3 * r + 1] * M[3 + cc] + H[3 * r + 2] * M[6 + cc];
+
+        // ---- M = R S': d(log scale_k) = (R^T dM)_kk * scale_mod * s_k
+        for (int k = 0; k < 3; k++) {
+            const double dS_kk = R[k] * dM[k] + R[3 + k] * dM[3 + k] + R[6 + k] * dM[6 + k];
+            g_ls[k] = dS_kk * sm * sc[k];
+        }
+        // dR = dM S'^T
+        double dR[9];
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++)
+                dR[3 * r + cc] = dM[3 * r] * S[3 * cc] + dM[3 * r + 1] * S[3 * cc + 1] + dM[3 * r + 2] * S[3 * cc + 2];
+        // R = I + (2/n2) Q(q)  (normalise-then-divide-by-squared-norm is scale invariant)
+        {
+            double QD = 0.0;
+            for (int k = 0; k < 9; k++) QD += Q[k] * dR[k];
+            const double D00 = dR[0], D01 = dR[1], D02 = dR[2], D10 = dR[3], D11 = dR[4], D12 = dR[5],
+                         D20 = dR[6], D21 = dR[7], D22 = dR[8];
+            const double pw = -qz * D01 + qy * D02 + qz * D10 - qx * D12 - qy * D20 + qx * D21;
+            const double px = qy * D01 + qz * D02 + qy * D10 - 2 * qx * D11 - qw * D12 + qz * D20 + qw * D21 - 2 * qx * D22;
+            const double py = -2 * qy * D00 + qx * D01 + qw * D02 + qx * D10 + qz * D12 - qw * D20 + qz * D21 - 2 * qy * D22;
+            const double pz = -2 * qz * D00 - qw * D01 + qx * D02 + qw * D10 - 2 * qz * D11 + qy * D12 + qx * D20 + qy * D21;
+            const double k2 = 2.0 * s * QD / n2;   // (4 QD / n2^2)
+            g_q[0] = s * pw - k2 * qw;
+            g_q[1] = s * px - k2 * qx;
+            g_q[2] = s * py - k2 * qy;
+            g_q[3] = s * pz - k2 * qz;
+        }
+        if (ROWS && opacity && opacity_is_logit) {     // opacity = sigmoid(parameter)
+            const float o = 1.0f / (1.0f + __expf(-opacity[i]));
+            g_op *= o * (1.0f - o);
+        }
     }
 
     if (accumulate) {
-        if (visible) {
+        if (any) {
             for (int k = 0; k < 3; k++) { dL_dmeans[3 * i + k] += (float)g_mean[k]; dL_dlog_scales[3 * i + k] += (float)g_ls[k]; }
             for (int k = 0; k < 4; k++) dL_dquats[4 * i + k] += (float)g_q[k];
+            if (ROWS && dL_dopacity) dL_dopacity[i] += g_op;
+#pragma unroll
+            for (int vv = 0; vv < 12; vv++) {
+                float4 w = out_sh[vv];
+                w.x += acc_sh[4 * vv]; w.y += acc_sh[4 * vv + 1]; w.z += acc_sh[4 * vv + 2]; w.w += acc_sh[4 * vv + 3];
+                out_sh[vv] = w;
+            }
         }
     } else {
         for (int k = 0; k < 3; k++) { dL_dmeans[3 * i + k] = (float)g_mean[k]; dL_dlog_scales[3 * i + k] = (float)g_ls[k]; }
         for (int k = 0; k < 4; k++) dL_dquats[4 * i + k] = (float)g_q[k];
+        if (ROWS && dL_dopacity) dL_dopacity[i] = g_op;
+#pragma unroll
+        for (int vv = 0; vv < 12; vv++)
+            out_sh[vv] = make_float4(acc_sh[4 * vv], acc_sh[4 * vv + 1], acc_sh[4 * vv + 2], acc_sh[4 * vv + 3]);
     }
+}
+
+int check_common(gs_ctx *ctx, int32_t N, const gs_camera *cam) {
+    GS_REQUIRE(ctx && cam, "gs_backward_params: ctx/cam is NULL");
+    GS_REQUIRE(N >= 0, "gs_backward_params: N=%d < 0", N);
+    GS_REQUIRE(cam->sh_degree >= 0 && cam->sh_degree <= 3, "gs_backward_params: sh_degree %d not in 0..3",
+               cam->sh_degree);
+    GS_REQUIRE(cam->res_w > 0 && cam->res_h > 0 && cam->cam_width > 0 && cam->cam_height > 0 && cam->fx > 0 &&
+                   cam->fy > 0, "gs_backward_params: invalid camera/frame description");
+    return GS_OK;
 }
 
 }  // namespace
@@ -232,24 +298,68 @@ extern "C" int gs_backward_params(gs_ctx *ctx, int32_t N, const float *means, co
                                   const int32_t *radii, const uint8_t *clamped, const float *dL_dcenters,
                                   const float *dL_dconics, const float *dL_dcolors, int32_t accumulate,
                                   float *dL_dmeans, float *dL_dlog_scales, float *dL_dquats, float *dL_dsh) {
-    GS_REQUIRE(ctx && cam, "gs_backward_params: ctx/cam is NULL");
-    GS_REQUIRE(N >= 0, "gs_backward_params: N=%d < 0", N);
-    GS_REQUIRE(cam->sh_degree >= 0 && cam->sh_degree <= 3, "gs_backward_params: sh_degree %d not in 0..3",
-               cam->sh_degree);
-    GS_REQUIRE(cam->res_w > 0 && cam->res_h > 0 && cam->cam_width > 0 && cam->cam_height > 0 && cam->fx > 0 &&
-                   cam->fy > 0, "gs_backward_params: invalid camera/frame description");
+    int rc = check_common(ctx, N, cam);
+    if (rc) return rc;
     if (N == 0) return GS_OK;
     GS_REQUIRE(means && log_scales && quats && sh && radii && clamped && dL_dcenters && dL_dconics &&
                    dL_dcolors && dL_dmeans && dL_dlog_scales && dL_dquats && dL_dsh,
                "gs_backward_params: NULL array argument");
     GS_REQUIRE(((uintptr_t)sh & 15) == 0 && ((uintptr_t)dL_dsh & 15) == 0,
                "gs_backward_params: sh and dL_dsh must be 16-byte aligned");
-    PreCam pc;
-    gs_make_precam(cam, &pc);
+    BatchArgs args;
+    memset(&args, 0, sizeof args);
+    args.n_views = 1;
+    gs_make_precam(cam, &args.v[0].cam);
+    args.v[0].radii = radii; args.v[0].clamped = clamped;
+    args.v[0].d_centers = dL_dcenters; args.v[0].d_conics = dL_dconics; args.v[0].d_colors = dL_dcolors;
     GS_HIP(hipSetDevice(ctx->device));
-    { gs_prof_scope prof_(ctx, GS_K_PARAM_BWD); hipLaunchKernelGGL(param_bwd_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
-                       log_scales, quats, sh, pc, radii, clamped, dL_dcenters, dL_dconics, dL_dcolors,
-                       accumulate, dL_dmeans, dL_dlog_scales, dL_dquats, dL_dsh); }
+    { gs_prof_scope prof_(ctx, GS_K_PARAM_BWD); hipLaunchKernelGGL(param_bwd_kernel<false>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
+                       log_scales, quats, sh, (const float *)nullptr, 0, args, accumulate, dL_dmeans, dL_dlog_scales,
+                       dL_dquats, (float *)nullptr, dL_dsh); }
     GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_backward_params_batch(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                                        const float *quats, const float *sh, const float *opacity,
+                                        int32_t opacity_is_logit, int32_t n_views, const gs_view_backward *views,
+                                        int32_t accumulate, float *dL_dmeans, float *dL_dlog_scales,
+                                        float *dL_dquats, float *dL_dopacity, float *dL_dsh) {
+    GS_REQUIRE(ctx, "gs_backward_params_batch: ctx is NULL");
+    GS_REQUIRE(N >= 0 && n_views >= 0, "gs_backward_params_batch: negative N or n_views");
+    GS_REQUIRE(n_views == 0 || views, "gs_backward_params_batch: views is NULL");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(means && log_scales && quats && sh && dL_dmeans && dL_dlog_scales && dL_dquats && dL_dsh,
+               "gs_backward_params_batch: NULL array argument");
+    GS_REQUIRE(((uintptr_t)sh & 15) == 0 && ((uintptr_t)dL_dsh & 15) == 0,
+               "gs_backward_params_batch: sh and dL_dsh must be 16-byte aligned");
+    for (int v = 0; v < n_views; v++) {
+        int rc = check_common(ctx, N, views[v].cam);
+        if (rc) return rc;
+        GS_REQUIRE(views[v].radii && views[v].clamped && views[v].grad_rows,
+                   "gs_backward_params_batch: view %d has a NULL array", v);
+        GS_REQUIRE(((uintptr_t)views[v].grad_rows & 15) == 0, "gs_backward_params_batch: grad_rows must be 16-byte aligned");
+        GS_REQUIRE(views[v].cam->res_h == views[0].cam->res_h,
+                   "gs_backward_params_batch: all views of a batch must share result_size (scale_mod)");
+    }
+    GS_HIP(hipSetDevice(ctx->device));
+    // chunks of MAX_BATCH_VIEWS views; the first chunk writes (unless accumulate), the rest add
+    int done = 0;
+    do {
+        BatchArgs args;
+        memset(&args, 0, sizeof args);
+        const int n = n_views - done < MAX_BATCH_VIEWS ? n_views - done : MAX_BATCH_VIEWS;
+        args.n_views = n;
+        for (int v = 0; v < n; v++) {
+            const gs_view_backward &src = views[done + v];
+            gs_make_precam(src.cam, &args.v[v].cam);
+            args.v[v].radii = src.radii; args.v[v].clamped = src.clamped; args.v[v].rows = src.grad_rows;
+        }
+        { gs_prof_scope prof_(ctx, GS_K_PARAM_BWD); hipLaunchKernelGGL(param_bwd_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
+                           log_scales, quats, sh, opacity, opacity_is_logit, args, (accumulate || done > 0) ? 1 : 0,
+                           dL_dmeans, dL_dlog_scales, dL_dquats, dL_dopacity, dL_dsh); }
+        GS_HIP(hipGetLastError());
+        done += n;
+    } while (done < n_views);
     return GS_OK;
 }

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import api
-from ._lib import check
+from ._lib import GsViewBackward, check
 
 GRAD_FLOATS = 59   # 3 mean + 3 log-scale + 4 quaternion + 1 opacity + 48 SH
 
@@ -91,24 +91,44 @@ class SplatPipeline:
         return image, state
 
     # ---- backward -----------------------------------------------------------------------
-    def backward(self, state, dL_dimage, grads, accumulate=True):
-        """Accumulates d(loss)/d(parameters) of one view into `grads` (FlatGrads)."""
+    def backward_rows(self, state, dL_dimage):
+        """K7 for one view: leaves the blend gradients in state["rows"] ([N,16], the kernel's
+        64-byte rows) for backward_params."""
         c = self.ctx
         c.sync_stream()
-        d_centers, d_conics, d_opac, d_colors = api.blend_backward(
-            c, state["centers"], state["colors"], state["opac"], state["conics"], state["binning"], self.bg,
-            self.pixel_offset, state["n_contrib"], state["t_final"], dL_dimage)
-        api.backward_params(c, self.means, self.log_scales, self.quats, self.sh, state["cam"], state["radii"],
-                            state["clamped"], d_centers, d_conics, d_colors,
-                            out=(grads.means, grads.log_scales, grads.quats, grads.sh), accumulate=accumulate)
-        if self.opacity_is_logit:
-            o = state["opac"]
-            d_opac = d_opac * o * (1.0 - o)
-        if accumulate:
-            grads.opacity += d_opac
-        else:
-            grads.opacity.copy_(d_opac)
+        b = state["binning"]
+        W, H = self.result_size
+        rows = torch.empty((self.N, 16), dtype=torch.float32, device=c.device)
+        check(c.lib.gs_blend_backward_rows(
+            c.handle, self.N, api._ptr(state["centers"]), api._ptr(state["colors"]), api._ptr(state["opac"]),
+            api._ptr(state["conics"]), api._ptr(b.vals), api._ptr(b.ranges), b.D, ctypes.byref(self.bg), W, H,
+            self.tile_size, self.pixel_offset, api._ptr(state["n_contrib"]), api._ptr(state["t_final"]),
+            api._ptr(dL_dimage.contiguous()), api._ptr(rows)), "gs_blend_backward_rows")
+        state["rows"] = rows
+        return rows
+
+    def backward_params(self, states, grads, accumulate=False):
+        """K8 over every view in `states` at once (each must have been through backward_rows):
+        parameters are read once and the gradients written (or added) once."""
+        c = self.ctx
+        c.sync_stream()
+        views = (GsViewBackward * max(len(states), 1))()
+        for k, st in enumerate(states):
+            views[k].cam = ctypes.pointer(st["cam"])
+            views[k].radii = st["radii"].data_ptr()
+            views[k].clamped = st["clamped"].data_ptr()
+            views[k].grad_rows = st["rows"].data_ptr()
+        check(c.lib.gs_backward_params_batch(
+            c.handle, self.N, api._ptr(self.means), api._ptr(self.log_scales), api._ptr(self.quats),
+            api._ptr(self.sh), api._ptr(self.opacity), int(self.opacity_is_logit), len(states), views,
+            int(bool(accumulate)), api._ptr(grads.means), api._ptr(grads.log_scales), api._ptr(grads.quats),
+            api._ptr(grads.opacity), api._ptr(grads.sh)), "gs_backward_params_batch")
         return grads
+
+    def backward(self, state, dL_dimage, grads, accumulate=True):
+        """d(loss)/d(parameters) of one view into `grads` (FlatGrads), added when accumulate."""
+        self.backward_rows(state, dL_dimage)
+        return self.backward_params([state], grads, accumulate=accumulate)
 
 
 def shard_views(n_views, rank, world_size):
@@ -128,13 +148,16 @@ def train_step(pipe, views, targets, grads, loss_scale=None):
     mine = shard_views(len(views), rank, world)
     W, H = pipe.result_size
     scale = (2.0 / (W * H * 3)) if loss_scale is None else loss_scale
-    grads.zero_()
     loss = torch.zeros((), dtype=torch.float32, device=pipe.ctx.device)
+    states = []
     for v in mine:
         image, state = pipe.forward(views[v])
         diff = image - targets[v]
         loss = loss + (diff * diff).mean()
-        pipe.backward(state, diff * scale, grads, accumulate=True)
+        pipe.backward_rows(state, diff * scale)
+        states.append(state)
+    # one pass over the gaussians for all local views; writes (not adds) every gradient
+    pipe.backward_params(states, grads, accumulate=False)
     if distributed and world > 1:
         dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
     return loss, len(mine)

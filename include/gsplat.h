@@ -128,6 +128,39 @@ int gs_backward_params(gs_ctx *ctx, int32_t N, const float *means, const float *
                        const float *dL_dconics, const float *dL_dcolors, int32_t accumulate,
                        float *dL_dmeans, float *dL_dlog_scales, float *dL_dquats, float *dL_dsh);
 
+/* Multi-view forms of the two backward entry points.  No counterpart in the reference, which
+ * trains one view per iteration (train.py:18-43); they serve SURVEY section 8(e): a rank renders
+ * its shard of the view batch, then converts all of its views' blend gradients to parameter
+ * gradients in ONE pass over the gaussians before the all-reduce.
+ *
+ * gs_blend_backward_rows: gs_blend_backward, but the result stays in the kernel's native layout,
+ * one 64-byte row per gaussian: grad_rows[N][16] = {d centre x,y (pixel units), d conic A,B,C,
+ * d opacity, d colour r,g,b, 7 unused}.  The call zeroes the rows, then accumulates.
+ *
+ * gs_backward_params_batch: gs_backward_params over n_views views at once (launches of up to 8
+ * views).  Parameters are read once, dL/dSigma is summed over the views before the
+ * Sigma -> (log-scale, quaternion) chain, gradients are written once (or += when accumulate).
+ * dL_dopacity[N] (may be NULL) receives the summed opacity gradient; when `opacity` is non-NULL
+ * and opacity_is_logit != 0 it is chained through opacity = sigmoid(parameter)
+ * (gaussian.py:50).  `views` is a HOST array; every view must share result_size. */
+typedef struct gs_view_backward {
+    const gs_camera *cam;       /* host */
+    const int32_t *radii;       /* device [N]    from gs_preprocess of that view */
+    const uint8_t *clamped;     /* device [N,3]  from gs_preprocess of that view */
+    const float *grad_rows;     /* device [N,16] from gs_blend_backward_rows of that view */
+} gs_view_backward;
+int gs_blend_backward_rows(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                           const float *opacities, const float *conics, const int32_t *vals,
+                           const int32_t *ranges, int64_t D, const float *background_host3,
+                           int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                           const int32_t *n_contrib, const float *t_final, const float *dL_dimage,
+                           float *grad_rows);
+int gs_backward_params_batch(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                             const float *quats, const float *sh, const float *opacity,
+                             int32_t opacity_is_logit, int32_t n_views, const gs_view_backward *views,
+                             int32_t accumulate, float *dL_dmeans, float *dL_dlog_scales,
+                             float *dL_dquats, float *dL_dopacity, float *dL_dsh);
+
 /* The reference's only native symbol (rasterize.c:27-28), kept as a compatibility shim with
  * HOST pointers and `double` conics (defect B7): blends one 16x16 tile on the device through the
  * same kernel as gs_blend_forward (pixel offset +0.5) and copies the chunk back.  Synchronous.

@@ -29,13 +29,14 @@ class FakePipe:
         self.calls.append(view)
         return img, {"view": view}
 
-    def backward(self, state, dL_dimage, grads, accumulate=True):
-        v = state["view"]
-        contrib = torch.arange(grads.flat.numel(), dtype=torch.float32) * (v + 1) + dL_dimage.sum()
-        if accumulate:
-            grads.flat += contrib
-        else:
-            grads.flat.copy_(contrib)
+    def backward_rows(self, state, dL_dimage):
+        state["dl_sum"] = dL_dimage.sum()
+
+    def backward_params(self, states, grads, accumulate=False):
+        if not accumulate:
+            grads.flat.zero_()
+        for st in states:
+            grads.flat += torch.arange(grads.flat.numel(), dtype=torch.float32) * (st["view"] + 1) + st["dl_sum"]
         return grads
 
 

@@ -342,3 +342,60 @@ def test_full_size_properties(gpu_ctx):
     _check_image(image.cpu().numpy().astype(np.float64), ref, fragile, "1M/1080p")
     ok = ~fragile.astype(bool)
     assert np.array_equal((st["n_contrib"].cpu().numpy() & 0x7FFFFFFF)[ok], lc[ok])
+
+
+def test_batched_multi_view_backward_vs_autograd_and_per_view_sum(gpu_ctx):
+    """gs_blend_backward_rows + gs_backward_params_batch (10 views: two launches of the batched
+    kernel) against (a) the sum of per-view single launches and (b) float64 autograd of the oracle
+    forward summed over the views, with logit opacities (gaussian.py:50)."""
+    import torch
+    import gsplat_amd as gs
+    d = load_scene("s1")
+    cam, R, t, g, rs, bg = scene_inputs(d)
+    rng = np.random.default_rng(11)
+    logit = np.float32(np.log(d["in_opacity"] / (1 - d["in_opacity"])))
+    import types
+    g2 = types.SimpleNamespace(center=g.center, scaling=g.scaling, rotation=g.rotation,
+                               spherical_harmonics=g.spherical_harmonics, opacity=logit, degrees=g.degrees)
+    pipe = gs.SplatPipeline(g2, rs, background=bg, pixel_offset=0.5, opacity_is_logit=True, ctx=gpu_ctx)
+    n_views = 10
+    views, wimgs = [], []
+    for k in range(n_views):
+        a = 0.03 * (k - 4)
+        Rk = np.asarray(R) @ np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        views.append(gs.View(cam, Rk, np.asarray(t) + np.array([0.01 * k, -0.02 * k, 0.05 * k])))
+        wimgs.append(rng.normal(size=(rs[0], rs[1], 3)).astype(np.float32))
+    states = []
+    for v, w in zip(views, wimgs):
+        _, st = pipe.forward(v)
+        pipe.backward_rows(st, torch.from_numpy(w).to(gpu_ctx.device))
+        states.append(st)
+    batch = gs.FlatGrads(pipe.N, gpu_ctx.device)
+    pipe.backward_params(states, batch, accumulate=False)
+    # (a) per-view launches accumulated
+    acc = gs.FlatGrads(pipe.N, gpu_ctx.device)
+    for st in states:
+        pipe.backward_params([st], acc, accumulate=True)
+    scale = acc.flat.abs().max().item()
+    assert scale > 0 and (batch.flat - acc.flat).abs().max().item() <= 2e-5 * scale
+    # accumulate=True on top of existing content
+    pipe.backward_params(states, acc, accumulate=True)
+    assert (acc.flat - 2 * batch.flat).abs().max().item() <= 4e-5 * scale
+    # (b) fp64 autograd over the first 3 views
+    sub = gs.FlatGrads(pipe.N, gpu_ctx.device)
+    pipe.backward_params(states[:3], sub, accumulate=False)
+    p = {k: torch.tensor(np.asarray(v, dtype=np.float32).astype(np.float64), requires_grad=True)
+         for k, v in (("c", g.center), ("s", g.scaling), ("r", g.rotation), ("sh", g.spherical_harmonics),
+                      ("o", logit))}
+    total = 0
+    for v, w in list(zip(views, wimgs))[:3]:
+        img, _ = ref_torch.render(p["c"], p["s"], p["r"], p["sh"], torch.sigmoid(p["o"]), int(d["in_degrees"]),
+                                  float(d["in_fx"]), float(d["in_fy"]), int(d["in_cam_w"]), int(d["in_cam_h"]),
+                                  v.camera_r, v.camera_t, rs, 16, d["in_bg"], 0.5)
+        total = total + (img * torch.tensor(w, dtype=torch.float64)).sum()
+    total.backward()
+    _assert_grad(sub.means.cpu().numpy(), p["c"].grad.numpy(), "batch d_means")
+    _assert_grad(sub.log_scales.cpu().numpy(), p["s"].grad.numpy(), "batch d_scales")
+    _assert_grad(sub.quats.cpu().numpy(), p["r"].grad.numpy(), "batch d_rots")
+    _assert_grad(sub.sh.cpu().numpy(), p["sh"].grad.numpy(), "batch d_sh")
+    _assert_grad(sub.opacity.cpu().numpy(), p["o"].grad.numpy(), "batch d_opacity(logit)")
