@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--views", type=int, default=8, help="global batch of views per step")
     ap.add_argument("--log-scale", type=float, nargs=2, default=(1.0, 3.0))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--concurrent-views", type=int, default=3, help="local views in flight on separate streams")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: single-view forward render")
     return ap.parse_args()
 
@@ -115,7 +116,7 @@ def main():
         if args.forward_only:
             image, _ = pipe.forward(views[0])
             return image
-        return gs.train_step(pipe, views, targets, grads)
+        return gs.train_step(pipe, views, targets, grads, concurrent_views=args.concurrent_views)
 
     def barrier():
         if world > 1:
@@ -125,16 +126,22 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.profile(True)
-    ctx.read_profile()
+    ctxs = [ctx] + ([c for c, _ in pipe.lanes(args.concurrent_views)] if args.concurrent_views > 1 else [])
+    for c in ctxs:
+        c.profile(True)
+        c.read_profile()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = ctx.read_profile()
-    ctx.profile(False)
+    prof = {}
+    for c in ctxs:
+        for k, (ms, cnt) in c.read_profile().items():
+            a = prof.get(k, (0.0, 0))
+            prof[k] = (a[0] + ms, a[1] + cnt)
+        c.profile(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -223,7 +230,8 @@ def main():
                        "gaussians": N, "views_per_step": n_views, "width": W, "height": H, "tile": 16,
                        "log_scale_range": list(args.log_scale), "seed": 20240601,
                        "n_visible": n_visible, "duplicates_D": int(D), "visited_D_star": d_star,
-                       "max_tile_list": max_len, "pixels_per_thread": 4},
+                       "max_tile_list": max_len, "pixels_per_thread": 4,
+                       "concurrent_views_per_rank": args.concurrent_views},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)

@@ -401,6 +401,27 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 geo, const floa
 // order, so a wave-level fence is all that staging -> broadcast reads needs.
 constexpr int QUAD_WAVES = 4;
 
+// Diagnostic build only (-DGS_STAMPS, tools/stamp_blend.py): per-wave start/end times and placement,
+// written to a buffer nothing else reads.  No stamp executes in the product build.
+#ifdef GS_STAMPS
+constexpr int STAMP_TILES = 65536;
+__device__ unsigned long long gs_stamps[2][STAMP_TILES][4];
+#define GS_STAMP_BEGIN() const unsigned long long stamp_t0_ = __builtin_amdgcn_s_memrealtime()
+#define GS_STAMP_END(which, work)                                                                   \
+    do {                                                                                            \
+        if ((threadIdx.x & 63) == 0 && tile < STAMP_TILES) {                                        \
+            gs_stamps[which][tile][0] = stamp_t0_;                                                  \
+            gs_stamps[which][tile][1] = __builtin_amdgcn_s_memrealtime();                           \
+            gs_stamps[which][tile][2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | \
+                                        __builtin_amdgcn_s_getreg(63492);                           \
+            gs_stamps[which][tile][3] = (unsigned long long)(work);                                 \
+        }                                                                                           \
+    } while (0)
+#else
+#define GS_STAMP_BEGIN()
+#define GS_STAMP_END(which, work)
+#endif
+
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -409,7 +430,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
 
-__global__ __launch_bounds__(64 * QUAD_WAVES) void blend_fwd_quad_kernel(QuadArgs a, float *__restrict__ image,
+// waves per SIMD the register allocator must leave room for (measured: spilling to reach more
+// resident waves costs more than it gains)
+#ifndef GS_FWD_WAVES
+#define GS_FWD_WAVES 8
+#endif
+__global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_kernel(QuadArgs a, float *__restrict__ image,
                                                                          int32_t *__restrict__ n_contrib,
                                                                          float *__restrict__ t_final) {
     __shared__ float4 s_geo_[QUAD_WAVES][64];
@@ -419,6 +445,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES) void blend_fwd_quad_kernel(QuadArg
     const int wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * QUAD_WAVES + wv;
     if (tile >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
+    GS_STAMP_BEGIN();
     float4 *s_geo = s_geo_[wv], *s_con = s_con_[wv], *s_rgb = s_rgb_[wv];
     const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
     const int lane = threadIdx.x & 63;
@@ -520,6 +547,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES) void blend_fwd_quad_kernel(QuadArg
             t_final[pidx] = T[k];
         }
     }
+    GS_STAMP_END(0, len);
 }
 
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -528,7 +556,10 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(64 * QUAD_WAVES) void blend_bwd_quad_kernel(QuadArgs a,
+#ifndef GS_BWD_WAVES
+#define GS_BWD_WAVES 5
+#endif
+__global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_kernel(QuadArgs a,
                                                                          const int32_t *__restrict__ n_contrib,
                                                                          const float *__restrict__ t_final,
                                                                          const float *__restrict__ dL_dimage,
@@ -541,6 +572,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES) void blend_bwd_quad_kernel(QuadArg
     const int wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * QUAD_WAVES + wv;
     if (tile >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
+    GS_STAMP_BEGIN();
     float4 *s_geo = s_rec_[wv][0], *s_con = s_rec_[wv][1], *s_rgb = s_rec_[wv][2];
     const float *s_flat = reinterpret_cast<const float *>(s_rec_[wv]);
     const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
@@ -701,7 +733,15 @@ __global__ __launch_bounds__(64 * QUAD_WAVES) void blend_bwd_quad_kernel(QuadArg
             }
         }
     }
+    GS_STAMP_END(1, max_end);
 }
+
+#ifdef GS_STAMPS
+extern "C" int gs_debug_read_stamps(int which, unsigned long long *host, int ntiles) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gs_stamps), (size_t)ntiles * 32, (size_t)which * STAMP_TILES * 32,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
 
 // grad rows -> the reference's four arrays (gpu_rasterize return tuple, rasterization.py:105)
 __global__ __launch_bounds__(256) void unpack_rows_kernel(int N, const float *__restrict__ rows,

@@ -58,10 +58,19 @@ class SplatPipeline:
         self.pixel_offset = float(pixel_offset)
         self.opacity_is_logit = bool(opacity_is_logit)
         self.stats = {}
+        self._lanes = []
+
+    def lanes(self, n):
+        """n (DeviceContext, torch stream) pairs for rendering independent views concurrently: each
+        lane owns its workspace arena and stream, so one view's blend tail overlaps another view's
+        preprocess/binning.  The parameters are shared (read-only during a step)."""
+        while len(self._lanes) < n:
+            self._lanes.append((api.DeviceContext(self.ctx.device_index), torch.cuda.Stream(self.ctx.device)))
+        return self._lanes[:n]
 
     # ---- forward ------------------------------------------------------------------------
-    def forward(self, view, want_keys=False):
-        c = self.ctx
+    def forward(self, view, want_keys=False, ctx=None):
+        c = ctx or self.ctx
         c.sync_stream()
         dev, N, f32, i32 = c.device, self.N, torch.float32, torch.int32
         W, H = self.result_size
@@ -85,7 +94,7 @@ class SplatPipeline:
         opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
         image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
                                                       self.pixel_offset)
-        state = dict(cam=cam, centers=centers, colors=colors, conics=conics, clamped=clamped, radii=radii,
+        state = dict(ctx=c, cam=cam, centers=centers, colors=colors, conics=conics, clamped=clamped, radii=radii,
                      opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final)
         self.stats = dict(D=binning.D)
         return image, state
@@ -93,8 +102,8 @@ class SplatPipeline:
     # ---- backward -----------------------------------------------------------------------
     def backward_rows(self, state, dL_dimage):
         """K7 for one view: leaves the blend gradients in state["rows"] ([N,16], the kernel's
-        64-byte rows) for backward_params."""
-        c = self.ctx
+        64-byte rows) for backward_params.  Runs on the ctx (lane) the view was rendered on."""
+        c = state.get("ctx", self.ctx)
         c.sync_stream()
         b = state["binning"]
         W, H = self.result_size
@@ -136,10 +145,11 @@ def shard_views(n_views, rank, world_size):
     return [v for v in range(n_views) if v % world_size == rank]
 
 
-def train_step(pipe, views, targets, grads, loss_scale=None):
+def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2):
     """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
-    match; the loss is mean squared error summed over views.  Returns (sum of local losses as a
+    match; the loss is mean squared error summed over views.  concurrent_views > 1 renders that
+    many local views at a time on separate streams.  Returns (sum of local losses as a
     device scalar, number of local views)."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -150,12 +160,34 @@ def train_step(pipe, views, targets, grads, loss_scale=None):
     scale = (2.0 / (W * H * 3)) if loss_scale is None else loss_scale
     loss = torch.zeros((), dtype=torch.float32, device=pipe.ctx.device)
     states = []
-    for v in mine:
-        image, state = pipe.forward(views[v])
-        diff = image - targets[v]
-        loss = loss + (diff * diff).mean()
-        pipe.backward_rows(state, diff * scale)
-        states.append(state)
+    n_lanes = min(int(concurrent_views), len(mine)) if hasattr(pipe, "lanes") else 1
+    if n_lanes > 1:
+        # independent views alternate between lanes (stream + workspace each); a lane's host sync
+        # (the duplicate count D) only waits for that lane
+        main = torch.cuda.current_stream(pipe.ctx.device)
+        lanes = pipe.lanes(n_lanes)
+        for _, stream in lanes:
+            stream.wait_stream(main)
+        parts = []
+        for k, v in enumerate(mine):
+            ctx, stream = lanes[k % n_lanes]
+            with torch.cuda.stream(stream):
+                image, state = pipe.forward(views[v], ctx=ctx)
+                diff = image - targets[v]
+                parts.append((diff * diff).mean())
+                pipe.backward_rows(state, diff * scale)
+            states.append(state)
+        for _, stream in lanes:
+            main.wait_stream(stream)
+        for part in parts:
+            loss = loss + part
+    else:
+        for v in mine:
+            image, state = pipe.forward(views[v])
+            diff = image - targets[v]
+            loss = loss + (diff * diff).mean()
+            pipe.backward_rows(state, diff * scale)
+            states.append(state)
     # one pass over the gaussians for all local views; writes (not adds) every gradient
     pipe.backward_params(states, grads, accumulate=False)
     if distributed and world > 1:
