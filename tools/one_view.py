@@ -1,4 +1,5 @@
-"""Run a few forward+backward views of the bench scene (for rocprofv3 --pmc passes)."""
+"""A few forward+backward views of the bench scene on ONE stream (for rocprofv3 --pmc passes, where
+per-kernel counters must not overlap).  GS_VIEWS views, then one batched parameter backward."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,8 +14,11 @@ pipe = gs.SplatPipeline(g, [W, H], ctx=ctx)
 views = make_views(gs, cam, 8)
 grads = gs.FlatGrads(N, ctx.device)
 target = torch.rand(W, H, 3, device=ctx.device)
+states = []
 for v in range(int(os.environ.get("GS_VIEWS", 2))):
     image, st = pipe.forward(views[v])
-    pipe.backward(st, (image - target) * 1e-6, grads)
+    pipe.backward_rows(st, (image - target) * 1e-6)
+    states.append(st)
+pipe.backward_params(states, grads)
 torch.cuda.synchronize()
 print("done", st["binning"].D)
