@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: forward+backward training step over an 8-view batch of
-1M synthetic gaussians at 1920x1080 (BASELINE.json configs[2]; single-GPU N=1 runs the whole batch).
+"""Benchmark of the hot path: forward+backward training step over an 8-view batch per GPU of
+1M synthetic gaussians at 1920x1080 (BASELINE.json configs[2]).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU; the 8 views of the batch are sharded round-robin over the ranks (strong
-scaling: the global batch is fixed); per-gaussian gradients [N*59] fp32 are summed with one RCCL
-all-reduce inside the timed region.  A step = preprocess -> binning/sort -> blend forward -> MSE loss
-gradient -> blend backward -> parameter backward for every local view, then the all-reduce.
+One process per GPU.  Weak scaling: every rank renders 8 views per step (global batch 8*N views,
+sharded round-robin over the ranks; --views-per-rank 0 --views 8 gives the fixed 8-view global batch
+instead); per-gaussian gradients [N*59] fp32 are summed with one RCCL all-reduce inside the timed
+region.  A step = for every local view preprocess -> binning/sort -> blend forward -> MSE loss
+gradient -> blend backward, then ONE batched parameter backward over the local views, then the
+all-reduce.
 Rank 0 prints ONE JSON line (contract in the task statement).  Synthetic inputs follow SURVEY.md
 section 8(d), seed 20240601; they are resident in HBM before the timed region starts.
 """
@@ -38,7 +40,8 @@ def parse():
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--views", type=int, default=8, help="global batch of views per step")
+    ap.add_argument("--views-per-rank", type=int, default=8, help="views each rank renders per step (weak scaling)")
+    ap.add_argument("--views", type=int, default=0, help="fixed GLOBAL batch instead (strong scaling; needs --views-per-rank 0)")
     ap.add_argument("--log-scale", type=float, nargs=2, default=(1.0, 3.0))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrent-views", type=int, default=3, help="local views in flight on separate streams")
@@ -102,7 +105,8 @@ def main():
     g, cam = make_scene(N, W, H, args.log_scale)
     ctx, queue, program = gs.setup_gpu(local_rank)
     pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx)
-    n_views = 1 if args.forward_only else args.views
+    weak = args.views_per_rank > 0
+    n_views = 1 if args.forward_only else (args.views_per_rank * world if weak else args.views)
     views = make_views(gs, cam, n_views)
     grads = gs.FlatGrads(N, dev)
     mine = gs.shard_views(n_views, rank, world)
@@ -193,6 +197,15 @@ def main():
                     "avg_launch_ms": round(dur_s * 1e3, 4), "algorithmic_bytes_per_launch": int(ab) if ab else None,
                     "note": "blend kernels are FP32-VALU bound (no dense contraction, no MFMA); "
                             "valu_* fields price the same launch against the vector-FP32 peak"}
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
+        # separately with rocprofv3 --pmc on the same scene (tools/one_view.py, tools/pmc_summary.py)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            if N == 1_000_000 and (W, H) == (1920, 1080) and dom in pmc and "hbm_traffic_bytes" in pmc[dom]:
+                roofline["traffic"] = int(pmc[dom]["hbm_traffic_bytes"])
+                roofline["traffic_source"] = "profiles/r01_pmc_summary.json"
+        except (OSError, ValueError):
+            pass
         if dom in ("blend_forward", "blend_backward"):
             flop_per_pair = 26 if dom == "blend_forward" else 70
             tf = pairs * flop_per_pair / dur_s / 1e12
@@ -201,20 +214,25 @@ def main():
                              "valu_peak_tflops": FP32_VALU_PEAK_TFLOPS,
                              "valu_frac_est": round(tf / FP32_VALU_PEAK_TFLOPS, 4)})
 
-    # ---- CPU baseline: restatement of rasterize.c on the host cores (rank 0, N=1 only)
+    # ---- CPU baseline: restatement of rasterize.c on the host cores (rank 0, N=1 only), bounded sample
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cref
-        a = [st[k].cpu().numpy() for k in ("centers", "colors", "opac", "conics")]
-        vals, rng_np = st["binning"].vals.cpu().numpy(), ranges.cpu().numpy()
-        t1 = time.perf_counter()
-        _, _, _, _, used = cref.rasterize_frame(a[0], a[1], a[2], a[3], vals, rng_np, [W, H], (0, 0, 0),
-                                                pixel_offset=0.5, margin=0.0)
-        cpu_s = time.perf_counter() - t1
-        cpu_baseline = {"value": round(P / 1e6 / cpu_s, 3), "unit": "Mpix/s (forward blend only)",
+        n_cpu_views, cpu_s, used = min(4, n_views), 0.0, 1
+        for v in range(n_cpu_views):
+            _, sv = pipe.forward(views[v])
+            torch.cuda.synchronize()
+            a = [sv[k].cpu().numpy() for k in ("centers", "colors", "opac", "conics")]
+            vals_np, rng_np = sv["binning"].vals.cpu().numpy(), sv["binning"].ranges.cpu().numpy()
+            t1 = time.perf_counter()
+            _, _, _, _, used = cref.rasterize_frame(a[0], a[1], a[2], a[3], vals_np, rng_np, [W, H], (0, 0, 0),
+                                                    pixel_offset=0.5, margin=0.0)
+            cpu_s += time.perf_counter() - t1
+        cpu_baseline = {"value": round(n_cpu_views * P / 1e6 / cpu_s, 3), "unit": "Mpix/s (forward blend only)",
                         "cores": int(used), "kind": "port",
-                        "sample": f"1 view {W}x{H} forward blend of the same scene (D={D}), fp64 POSIX "
-                                  f"restatement of rasterize.c, OpenMP over tiles, {cpu_s:.2f} s; host has "
+                        "sample": f"{n_cpu_views} views {W}x{H}, forward blend only (the reference's rasterize.c has no "
+                                  f"backward), same scene and tile lists (D={D}), fp64 POSIX restatement of rasterize.c, "
+                                  f"OpenMP over tiles, {cpu_s:.2f} s wall on {int(used)} threads; host has "
                                   f"{os.cpu_count()} logical CPUs"}
 
     if rank == 0:
@@ -222,10 +240,10 @@ def main():
             "metric": "Mpix/s fwd+bwd at 1M gaussians 1080p" if not args.forward_only else "Mpix/s forward at 1M gaussians 1080p",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[2]: fwd+bwd training step, %d gaussians, %d-view batch at %dx%d, "
-                                    "views sharded over ranks, RCCL all-reduce of [N*59] fp32 grads"
-                                    % (N, n_views, W, H)) if not args.forward_only else
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("configs[2]: fwd+bwd training step, %d gaussians, %d views per GPU per step at %dx%d "
+                                    "(global batch %d views sharded over %d rank(s)), RCCL all-reduce of [N*59] fp32 grads"
+                                    % (N, len(mine), W, H, n_views, world)) if not args.forward_only else
                                    "configs[1]: single %dx%d view forward, %d gaussians" % (W, H, N),
                        "gaussians": N, "views_per_step": n_views, "width": W, "height": H, "tile": 16,
                        "log_scale_range": list(args.log_scale), "seed": 20240601,
