@@ -15,6 +15,7 @@
 // pair), not by HBM or MFMA: no stage is a dense contraction.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -759,13 +760,19 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(int N, const float *__
 }
 
 // packs the caller's four arrays into the ctx-owned record arrays and fills QuadArgs
-int fill_quad(QuadArgs &q, const BlendArgs &a, gs_ctx *ctx, int32_t N) {
+// reuse = the caller is gs_blend_backward*: it must be given the arrays of the forward call whose
+// n_contrib/t_final it consumes, so the records packed by that forward call are still valid.
+int fill_quad(QuadArgs &q, const BlendArgs &a, gs_ctx *ctx, int32_t N, bool reuse = false) {
     const size_t n16 = ((size_t)(N > 0 ? N : 1) * sizeof(float4) + 255) & ~(size_t)255;
     int rc = gs_buf_reserve(ctx, &ctx->packed, 3 * n16);
     if (rc) return rc;
     char *base = (char *)ctx->packed.p;
     float4 *geo = (float4 *)base, *con = (float4 *)(base + n16), *rgb = (float4 *)(base + 2 * n16);
-    if (N > 0) {
+    const void *key[4] = {a.centers, a.colors, a.opacities, a.conics};
+    const bool cached = reuse && ctx->packed_N == N && memcmp(key, ctx->packed_key, sizeof key) == 0;
+    memcpy(ctx->packed_key, key, sizeof key);
+    ctx->packed_N = N;
+    if (N > 0 && !cached) {
         gs_prof_scope prof_(ctx, GS_K_PACK);
         hipLaunchKernelGGL(pack_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, a.centers, a.colors,
                            a.opacities, a.conics, geo, con, rgb);
@@ -838,7 +845,7 @@ int blend_backward_into_rows(gs_ctx *ctx, const BlendArgs &a, int32_t N, int64_t
         case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
         default: {
             QuadArgs q;
-            if ((rc = fill_quad(q, a, ctx, N))) return rc;
+            if ((rc = fill_quad(q, a, ctx, N, true))) return rc;
             gs_prof_scope prof_(ctx, GS_K_BLEND_BWD);
             hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
         } break;

@@ -68,6 +68,9 @@ struct gs_ctx {
     int32_t bin_N = -1;
     int64_t bin_D = -1;
     uint32_t bin_max_depth = 0;
+    // arrays the packed blend records were built from (gs_blend_forward -> gs_blend_backward reuse)
+    const void *packed_key[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t packed_N = -1;
 };
 
 int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);

@@ -94,7 +94,7 @@ class SplatPipeline:
         opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
         image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
                                                       self.pixel_offset)
-        state = dict(ctx=c, cam=cam, centers=centers, colors=colors, conics=conics, clamped=clamped, radii=radii,
+        state = dict(ctx=c, cam=cam, depths=depths, centers=centers, colors=colors, conics=conics, clamped=clamped, radii=radii,
                      opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final)
         self.stats = dict(D=binning.D)
         return image, state
