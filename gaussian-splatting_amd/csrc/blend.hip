@@ -32,7 +32,8 @@ struct BlendArgs {
     const int32_t *vals;
     const int2 *ranges;
     float bg[3];
-    int W, H, tiles_y;
+    int W, H, tiles_y;       // tiles_y: 16-pixel blocks per column of the frame
+    int list_tiles_y, shift; // the caller's tile grid: tile_size = 16 << shift, ranges[tx_T * list_tiles_y + ty_T]
     float pixel_offset;
 };
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256 / PPT) void blend_fwd_kernel(BlendArgs a, float
     const int lx = t / YQ, yq = t % YQ;
     const int px = tx * TILE + lx, py0 = ty * TILE + yq * PPT;
     const float fx = (float)px - a.pixel_offset;   // dist_x = c.x - x + off
-    const int2 rg = a.ranges[tile];
+    const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
     const int len = rg.y - rg.x;
 
     float fy[PPT], T[PPT], C[PPT][3];
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256 / PPT) void blend_bwd_kernel(BlendArgs a, const
     const int lx = t / YQ, yq = t % YQ;
     const int px = tx * TILE + lx, py0 = ty * TILE + yq * PPT;
     const float fx = (float)px - a.pixel_offset;
-    const int2 rg = a.ranges[tile];
+    const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
 
     float fy[PPT], T[PPT], Tf_bg[PPT], dLp[PPT][3], acc_rec[PPT][3], last_col[PPT][3], last_alpha[PPT];
     int end_k[PPT];
@@ -351,6 +352,7 @@ struct QuadArgs {
     const int2 *ranges;
     float bg[3];
     int W, H, tiles_y, ntiles;
+    int list_tiles_y, shift;
     float pixel_offset;
 };
 
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
     const float fx0 = (float)(X0 + qx) - off, fx1 = fx0 + 8.0f;
     const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
     const float xlo = (float)X0 - off, xhi = xlo + 15.0f, ylo = (float)Y0 - off, yhi = ylo + 15.0f;
-    const int2 rg = a.ranges[tile];
+    const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
     const int len = rg.y - rg.x;
 
     float T[4], C[4][3];
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     const float fx0 = (float)(X0 + qx) - off, fx1 = fx0 + 8.0f;
     const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
     const float xlo = (float)X0 - off, xhi = xlo + 15.0f, ylo = (float)Y0 - off, yhi = ylo + 15.0f;
-    const int2 rg = a.ranges[tile];
+    const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
 
     // lane 15 of row r finishes gradient words r and 4+r; the factors undo the log2 pre-scaling
     // (d power/d(.) = ln2 * d power2/d(.)) and map (a',b',c') back to the conic (A,B,C)
@@ -780,6 +782,7 @@ int fill_quad(QuadArgs &q, const BlendArgs &a, gs_ctx *ctx, int32_t N, bool reus
     q.geo = geo; q.con = con; q.rgb = rgb; q.vals = a.vals; q.ranges = a.ranges;
     q.bg[0] = a.bg[0]; q.bg[1] = a.bg[1]; q.bg[2] = a.bg[2];
     q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
+    q.list_tiles_y = a.list_tiles_y; q.shift = a.shift;
     q.ntiles = gs_div_up(a.W, TILE) * a.tiles_y;
     return GS_OK;
 }
@@ -788,7 +791,10 @@ int fill_args(BlendArgs &a, gs_ctx *ctx, int32_t N, const float *centers, const 
               const float *opacities, const float *conics, const int32_t *vals, const int32_t *ranges,
               int64_t D, const float *bg, int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset) {
     GS_REQUIRE(ctx, "gs_blend: ctx is NULL");
-    GS_REQUIRE(tile_size == TILE, "gs_blend: tile_size %d unsupported (only 16, rasterize.c:5)", tile_size);
+    int shift = 0;
+    while ((TILE << shift) < tile_size && shift < 8) shift++;
+    GS_REQUIRE((TILE << shift) == tile_size, "gs_blend: tile_size %d unsupported (16 = rasterize.c:5, 32 = "
+               "gaussian.py:44-50, or 16 << k)", tile_size);
     GS_REQUIRE(res_w > 0 && res_h > 0, "gs_blend: invalid frame %dx%d", res_w, res_h);
     GS_REQUIRE(N >= 0 && D >= 0, "gs_blend: negative N or D");
     GS_REQUIRE(ranges && bg, "gs_blend: ranges/background is NULL");
@@ -800,6 +806,7 @@ int fill_args(BlendArgs &a, gs_ctx *ctx, int32_t N, const float *centers, const 
     a.ranges = reinterpret_cast<const int2 *>(ranges);
     a.bg[0] = bg[0]; a.bg[1] = bg[1]; a.bg[2] = bg[2];
     a.W = res_w; a.H = res_h; a.tiles_y = gs_div_up(res_h, TILE);
+    a.list_tiles_y = gs_div_up(res_h, tile_size); a.shift = shift;
     a.pixel_offset = pixel_offset;
     return GS_OK;
 }

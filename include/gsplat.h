@@ -9,7 +9,8 @@
  *   - one ctx per stream; calls on one ctx are serialised by the caller; ctxs are independent;
  *   - images are [W][H][3] x-major exactly as the reference (rasterize.c:93,130,
  *     rasterization.py:29,96,122);
- *   - only tile_size == 16 is supported by the blend kernels (rasterize.c:5 TILE_SIZE).
+ *   - the blend kernels take tile_size 16 (rasterize.c:5 TILE_SIZE), 32 (the render entry,
+ *     gaussian.py:44-50) or any 16 << k: a tile is blended as 16x16 blocks sharing its list.
  *
  * Each entry point cites the reference interface it replaces (file:line under the reference).
  */

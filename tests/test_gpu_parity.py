@@ -478,3 +478,43 @@ def test_config4_stress_4k_heavy_overlap(gpu_ctx):
     ga = gs.FlatGrads(pipe.N, image.device)
     pipe.backward(st, torch.ones_like(image), ga, accumulate=False)
     assert bool(torch.isfinite(ga.flat).all()) and ga.flat.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("name", ["s1", "s3"])
+def test_tile_size_32_render_path(gpu_ctx, name):
+    """tile_size=32 is what the reference's render entry uses (gaussian.py:44-50).  K1 rects and
+    binning bit-exact against the oracle at tile 32; image and gradients against the fp64 oracle
+    blend over 32x32 tiles (each 32-tile is blended as four 16x16 blocks sharing its list)."""
+    import torch
+    import gsplat_amd as gs
+    d = load_scene(name)
+    cam, R, t, g, rs, bg = scene_inputs(d)
+    out = gs.forward_pass(gpu_ctx, None, None, cam, R, t, g, result_size=rs, tile_size=32, training=False)
+    centers, depths, colors, conics, tiles_touched, radii = out
+    o = ref_np.preprocess(np.float32(g.center), np.float32(g.scaling), np.float32(g.rotation),
+                          np.float32(g.spherical_harmonics), int(g.degrees), cam.params[0], cam.params[1],
+                          cam.width, cam.height, R, t, rs, 32)
+    assert np.array_equal(tiles_touched, o["tiles_touched"]) and np.array_equal(depths, o["depths"])
+    b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tiles_touched, radii, depths, result_size=rs, tile_size=32)
+    keys, vals, ranges = ref_np.bin_duplicates(o["tiles_touched"], o["depths"], rs, 32)
+    assert np.array_equal(b.keys.cpu().numpy().view(np.uint64), keys)
+    assert np.array_equal(b.vals.cpu().numpy(), vals) and np.array_equal(b.ranges.cpu().numpy(), ranges)
+    rng = np.random.default_rng(3)
+    wimg = rng.normal(size=(rs[0], rs[1], 3)).astype(np.float32)
+    image, d_colors, d_centers, d_conics, d_opac = gs.gpu_rasterize(
+        gpu_ctx, None, None, centers, colors, g.opacity, conics, b, training=True, result_size=rs, tile_size=32,
+        background_color=bg, dL_dimage=wimg, pixel_offset=0.5)
+    p = {k: torch.tensor(np.asarray(d[k], dtype=np.float32).astype(np.float64), requires_grad=True)
+         for k in ("in_center", "in_scaling", "in_rotation", "in_sh", "in_opacity")}
+    img, aux = ref_torch.render(p["in_center"], p["in_scaling"], p["in_rotation"], p["in_sh"], p["in_opacity"],
+                                int(d["in_degrees"]), float(d["in_fx"]), float(d["in_fy"]), int(d["in_cam_w"]),
+                                int(d["in_cam_h"]), d["in_R"], d["in_t"], rs, 32, d["in_bg"], 0.5)
+    for k in ("centers", "conics", "colors"):
+        aux[k].retain_grad()
+    (img * torch.tensor(wimg, dtype=torch.float64)).sum().backward()
+    ref = img.detach().numpy()
+    err = np.abs(image - ref)
+    assert (err > IMG_ATOL + IMG_RTOL * np.abs(ref)).mean() < 5e-3 and err.max() < 0.02   # rare branch flips only
+    _assert_grad(d_colors, aux["colors"].grad.numpy(), "d_colors t32", tol=2e-3)
+    _assert_grad(d_conics, aux["conics"].grad.numpy(), "d_conics t32", tol=2e-3)
+    _assert_grad(d_opac, p["in_opacity"].grad.numpy(), "d_opacity t32", tol=2e-3)
