@@ -54,6 +54,9 @@ SIGNATURES = {
                                               _I32, _I32, _I32, _F, _P, _P, _P, _P]),
     "gs_backward_params_batch": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, _I32,
                                                 ctypes.POINTER(GsViewBackward), _I32, _P, _P, _P, _P, _P]),
+    "gs_image_loss": (ctypes.c_int, [_P, _I64, _P, _P, _I32, _F, _I32, _P, _P]),
+    "gs_adam_step": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(_F * 5),
+                                    _F, _F, _F, _I32, _I32, _F]),
     "rasterize_tile": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
 }

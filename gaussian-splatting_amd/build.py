@@ -17,6 +17,7 @@ SOURCES = {
     "blend.hip": ["-fno-slp-vectorize"],
     "param_bwd.hip": [],
     "tile_shim.hip": [],
+    "train.hip": [],
 }
 
 

@@ -29,7 +29,7 @@ int gs_set_error(int code, const char *fmt, ...);
 // per-kernel HIP-event timing (off by default; see gs_ctx_profile)
 enum gs_kernel_id {
     GS_K_PREPROCESS, GS_K_COUNT, GS_K_SCAN, GS_K_OFFSETS, GS_K_DUPLICATE, GS_K_SORT, GS_K_RANGES,
-    GS_K_BLEND_FWD, GS_K_BLEND_BWD, GS_K_UNPACK, GS_K_PARAM_BWD, GS_K_PACK, GS_K_DEPTH_SORT, GS_K_NUM
+    GS_K_BLEND_FWD, GS_K_BLEND_BWD, GS_K_UNPACK, GS_K_PARAM_BWD, GS_K_PACK, GS_K_DEPTH_SORT, GS_K_LOSS, GS_K_ADAM, GS_K_NUM
 };
 
 struct gs_prof_span {
@@ -59,6 +59,7 @@ struct gs_ctx {
     gs_buf packed;       // float4[3][N] packed per-gaussian blend attributes
     gs_buf grad_rows;    // float[N][16] 64-byte gradient rows for blend backward
     gs_buf tile_scratch; // rasterize_tile shim staging
+    gs_buf loss_partials; // f64[1024] per-block loss sums
     uint64_t *total_host = nullptr;   // pinned, 2 words
     // state carried from gs_bin_count to gs_bin_fill
     bool prof_on = false;

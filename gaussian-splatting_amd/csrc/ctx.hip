@@ -66,7 +66,7 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
 
 static const char *const k_kernel_names[GS_K_NUM] = {
     "preprocess", "bin_count", "bin_scan", "bin_offsets", "bin_duplicate", "bin_sort", "bin_ranges",
-    "blend_forward", "blend_backward", "grad_unpack", "param_backward", "blend_pack", "bin_depth_sort"};
+    "blend_forward", "blend_backward", "grad_unpack", "param_backward", "blend_pack", "bin_depth_sort", "image_loss", "adam_step"};
 
 static hipEvent_t prof_event(gs_ctx *c) {
     if (!c->prof_free.empty()) {
@@ -134,7 +134,7 @@ extern "C" int gs_ctx_destroy(gs_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     gs_buf *bufs[] = {&ctx->counts, &ctx->offsets, &ctx->block_sums, &ctx->total, &ctx->depth_sort,
                       &ctx->keys_tmp, &ctx->vals_tmp, &ctx->radix_table, &ctx->packed, &ctx->grad_rows,
-                      &ctx->tile_scratch};
+                      &ctx->tile_scratch, &ctx->loss_partials};
     for (gs_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (gs_prof_span &sp : ctx->prof_spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }

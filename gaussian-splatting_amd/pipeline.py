@@ -68,6 +68,12 @@ class SplatPipeline:
             self._lanes.append((api.DeviceContext(self.ctx.device_index), torch.cuda.Stream(self.ctx.device)))
         return self._lanes[:n]
 
+    def export(self):
+        """The current parameters as a host GaussianSet (float64 NumPy, the reference's dtypes)."""
+        f = lambda t: t.detach().cpu().numpy().astype(np.float64)
+        return api.GaussianSet(f(self.means), f(self.sh), f(self.log_scales), f(self.quats), f(self.opacity),
+                               self.degrees)
+
     # ---- forward ------------------------------------------------------------------------
     def forward(self, view, want_keys=False, ctx=None):
         c = ctx or self.ctx
@@ -98,6 +104,25 @@ class SplatPipeline:
                      opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final)
         self.stats = dict(D=binning.D)
         return image, state
+
+    # ---- loss ---------------------------------------------------------------------------
+    def image_loss(self, image, target, kind="l1", scale=1.0, loss_out=None, accumulate=False, ctx=None):
+        """Fused loss + dL/dimage (gs_image_loss): kind "l1" = mean|image-target| (the reference's
+        metric, train.py:49, computed in float), "l2" = mean squared error.  Returns
+        (dL_dimage[W,H,3], loss) with loss a 1-element device tensor (loss_out if given)."""
+        c = ctx or self.ctx
+        c.sync_stream()
+        image = image.contiguous()
+        target = target.contiguous()
+        if image.shape != target.shape or image.dtype != torch.float32 or target.dtype != torch.float32:
+            raise ValueError("image and target must be float32 tensors of the same shape")
+        dL = torch.empty_like(image)
+        if loss_out is None:
+            loss_out = torch.zeros(1, dtype=torch.float32, device=c.device)
+        check(c.lib.gs_image_loss(c.handle, image.numel(), api._ptr(image), api._ptr(target),
+                                  {"l1": 0, "l2": 1}[kind], float(scale), int(bool(accumulate)), api._ptr(dL),
+                                  api._ptr(loss_out)), "gs_image_loss")
+        return dL, loss_out
 
     # ---- backward -----------------------------------------------------------------------
     def backward_rows(self, state, dL_dimage):
@@ -145,10 +170,42 @@ def shard_views(n_views, rank, world_size):
     return [v for v in range(n_views) if v % world_size == rank]
 
 
-def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2):
+# main.py:11-17, in the order of the flat gradient buffer (means, log_scales, quats, opacity, sh)
+REFERENCE_LEARNING_RATES = {"center": .0008, "scaling": .025, "rotation": .005, "opacity": .25, "sh": .0125}
+
+
+class Optimizer:
+    """Parameter update on the flat [N*59] gradient buffer (gs_adam_step).  method "adam": Adam with
+    one learning rate per parameter group; "reference": the intent of train.py:51-56,
+    param -= lr * grad * loss."""
+
+    def __init__(self, pipe, learning_rates=None, method="adam", betas=(0.9, 0.999), eps=1e-15):
+        lr = dict(REFERENCE_LEARNING_RATES)
+        lr.update(learning_rates or {})
+        self.pipe, self.method, self.betas, self.eps = pipe, method, betas, float(eps)
+        self.lr = (ctypes.c_float * 5)(lr["center"], lr["scaling"], lr["rotation"], lr["opacity"], lr["sh"])
+        self.step_count = 0
+        n = pipe.N * GRAD_FLOATS
+        dev = pipe.ctx.device
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev) if method == "adam" else None
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev) if method == "adam" else None
+
+    def step(self, grads, loss=1.0):
+        p, c = self.pipe, self.pipe.ctx
+        c.sync_stream()
+        self.step_count += 1
+        check(c.lib.gs_adam_step(c.handle, p.N, api._ptr(p.means), api._ptr(p.log_scales), api._ptr(p.quats),
+                                 api._ptr(p.opacity), api._ptr(p.sh), api._ptr(grads.flat), api._ptr(self.m),
+                                 api._ptr(self.v), ctypes.byref(self.lr), float(self.betas[0]), float(self.betas[1]),
+                                 self.eps, self.step_count, 0 if self.method == "adam" else 1, float(loss)),
+              "gs_adam_step")
+
+
+def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2"):
     """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
-    match; the loss is mean squared error summed over views.  concurrent_views > 1 renders that
+    match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
+    formed together with dL/dimage by the fused native kernel.  concurrent_views > 1 renders that
     many local views at a time on separate streams.  Returns (sum of local losses as a
     device scalar, number of local views)."""
     import torch.distributed as dist
@@ -157,10 +214,24 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2)
     world = dist.get_world_size() if distributed else 1
     mine = shard_views(len(views), rank, world)
     W, H = pipe.result_size
-    scale = (2.0 / (W * H * 3)) if loss_scale is None else loss_scale
-    loss = torch.zeros((), dtype=torch.float32, device=pipe.ctx.device)
+    scale = 1.0 if loss_scale is None else loss_scale
     states = []
     n_lanes = min(int(concurrent_views), len(mine)) if hasattr(pipe, "lanes") else 1
+    native_loss = hasattr(pipe, "image_loss")
+    if not native_loss:        # duck-typed stand-ins (CPU tests): plain torch MSE
+        loss = torch.zeros((), dtype=torch.float32, device=pipe.ctx.device)
+        gscale = scale * 2.0 / (W * H * 3)
+        for v in mine:
+            image, state = pipe.forward(views[v])
+            diff = image - targets[v]
+            loss = loss + (diff * diff).mean()
+            pipe.backward_rows(state, diff * gscale)
+            states.append(state)
+        pipe.backward_params(states, grads, accumulate=False)
+        if distributed and world > 1:
+            dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
+        return loss, len(mine)
+    losses = torch.zeros(max(len(mine), 1), dtype=torch.float32, device=pipe.ctx.device)
     if n_lanes > 1:
         # independent views alternate between lanes (stream + workspace each); a lane's host sync
         # (the duplicate count D) only waits for that lane
@@ -168,26 +239,22 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2)
         lanes = pipe.lanes(n_lanes)
         for _, stream in lanes:
             stream.wait_stream(main)
-        parts = []
         for k, v in enumerate(mine):
             ctx, stream = lanes[k % n_lanes]
             with torch.cuda.stream(stream):
                 image, state = pipe.forward(views[v], ctx=ctx)
-                diff = image - targets[v]
-                parts.append((diff * diff).mean())
-                pipe.backward_rows(state, diff * scale)
+                dL, _ = pipe.image_loss(image, targets[v], loss_kind, scale, losses[k:k + 1], ctx=ctx)
+                pipe.backward_rows(state, dL)
             states.append(state)
         for _, stream in lanes:
             main.wait_stream(stream)
-        for part in parts:
-            loss = loss + part
     else:
-        for v in mine:
+        for k, v in enumerate(mine):
             image, state = pipe.forward(views[v])
-            diff = image - targets[v]
-            loss = loss + (diff * diff).mean()
-            pipe.backward_rows(state, diff * scale)
+            dL, _ = pipe.image_loss(image, targets[v], loss_kind, scale, losses[k:k + 1])
+            pipe.backward_rows(state, dL)
             states.append(state)
+    loss = losses.sum()
     # one pass over the gaussians for all local views; writes (not adds) every gradient
     pipe.backward_params(states, grads, accumulate=False)
     if distributed and world > 1:

@@ -162,6 +162,23 @@ int gs_backward_params_batch(gs_ctx *ctx, int32_t N, const float *means, const f
                              int32_t accumulate, float *dL_dmeans, float *dL_dlog_scales,
                              float *dL_dquats, float *dL_dopacity, float *dL_dsh);
 
+/* Training-loop side.
+ * gs_image_loss replaces train.py:45-49 (an L1 "loss" on uint8 copies that wraps around, defect
+ * B12, and no dL/dimage at all, defect B4): over n = W*H*3 floats, kind 0: loss = mean|image -
+ * target|, dL_dimage = scale*sign(diff)/n; kind 1: loss = mean diff^2, dL_dimage = scale*2*diff/n.
+ * loss_out[0] (device float) is written, or added to when accumulate != 0.
+ * gs_adam_step replaces the parameter update of train.py:51-56.  mode 0: Adam with bias
+ * correction for `step` (1-based), one learning rate per group in the order means, log_scales,
+ * quats, opacity, sh (main.py:11-17: .0008, .025, .005, .25, .0125); grad_flat / m_flat / v_flat are
+ * the flat [N*59] buffers laid out in that order.  mode 1: the reference's intent,
+ * param -= lr * grad * sgd_scale (sgd_scale = the L1 loss, train.py:52-56).  Non-finite gradients
+ * count as 0 (np.nan_to_num, train.py:52-55). */
+int gs_image_loss(gs_ctx *ctx, int64_t n, const float *image, const float *target, int32_t kind,
+                  float scale, int32_t accumulate, float *dL_dimage, float *loss_out);
+int gs_adam_step(gs_ctx *ctx, int32_t N, float *means, float *log_scales, float *quats, float *opacity,
+                 float *sh, const float *grad_flat, float *m_flat, float *v_flat, const float *lr_host5,
+                 float beta1, float beta2, float eps, int32_t step, int32_t mode, float sgd_scale);
+
 /* The reference's only native symbol (rasterize.c:27-28), kept as a compatibility shim with
  * HOST pointers and `double` conics (defect B7): blends one 16x16 tile on the device through the
  * same kernel as gs_blend_forward (pixel offset +0.5) and copies the chunk back.  Synchronous.
