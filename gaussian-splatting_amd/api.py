@@ -177,6 +177,29 @@ class GaussianSet:
         self.opacity = opacities
         self.degrees = degrees
 
+    def rasterize(self, camera, source_image, ctx, queue, program, file_output=None, result_size=[979, 546]):
+        """gaussian.py:39-52, the render entry of load_model.py: forward_pass -> match_gaus_to_tiles
+        -> gpu_rasterize(sigmoid(opacity)) at tile_size 32, saved as <file_output>.jpg when a name
+        is given.  Returns the image [W,H,3]."""
+        from .io import quat_to_rotmat
+        camera_r = quat_to_rotmat(source_image.qvec)                       # gaussian.py:41
+        camera_t = np.asarray(source_image.tvec, dtype=np.float64)
+        centers, depths, colors, conics, tiles_touched, radii = forward_pass(
+            ctx, queue, program, camera, camera_r, camera_t, self, result_size=result_size, training=False,
+            tile_size=32)
+        key_mapper = match_gaus_to_tiles(ctx, queue, program, tiles_touched, radii, depths, result_size=result_size,
+                                         tile_size=32)
+        op = self.opacity
+        op = torch.sigmoid(op) if _is_t(op) else 1.0 / (1.0 + np.exp(-np.asarray(op, dtype=np.float64)))   # functions.py:42
+        image = gpu_rasterize(ctx, queue, program, centers, colors, op, conics, key_mapper, result_size=result_size,
+                              training=False, tile_size=32)
+        if file_output:
+            from PIL import Image as PILImage
+            arr = image.detach().cpu().numpy() if _is_t(image) else image
+            PILImage.fromarray(np.swapaxes(np.uint8(np.clip(arr, 0, 1) * 255), 0, 1)).save(
+                "{output}.jpg".format(output=file_output))
+        return image
+
 
 def _gaussian_tensors(g, device):
     N = len(g.center)

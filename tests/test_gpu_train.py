@@ -127,3 +127,23 @@ def test_train_model_reduces_the_loss(gpu_ctx, tmp_path):
     ck = gs.load_gaussians(str(tmp_path / "iter_40_gaus"), degrees=1)
     np.testing.assert_array_equal(ck.center, out.center)
     assert out.center.shape == g.center.shape and not np.array_equal(out.center, start.center)
+
+
+def test_render_entry_from_ply(gpu_ctx, tmp_path):
+    """load_model.py:44-54 end to end: PLY -> GaussianSet.rasterize (tile 32, sigmoid opacities) -> jpg,
+    against the stage API called by hand."""
+    import gsplat_amd as gs
+    cam, R, t, g, rs = synth_scene(800, 203, 117, seed=12, fx=150.0, log_scale=(2.0, 3.0))
+    logit = np.log(g.opacity / (1 - g.opacity)).reshape(-1, 1)
+    gs.save_ply(str(tmp_path / "pc.ply"), gs.GaussianSet(g.center, g.spherical_harmonics, g.scaling, g.rotation, logit))
+    gaussians = gs.load_data(str(tmp_path / "pc.ply"))
+    src = types.SimpleNamespace(qvec=np.array([1.0, 0, 0, 0]), tvec=np.zeros(3))
+    img = gaussians.rasterize(cam, src, gpu_ctx, None, None, str(tmp_path / "out"), result_size=rs)
+    assert img.shape == (203, 117, 3) and (tmp_path / "out.jpg").exists()
+    c, d, col, con, tt, rad = gs.forward_pass(gpu_ctx, None, None, cam, np.eye(3), np.zeros(3), gaussians,
+                                              result_size=rs, training=False, tile_size=32)
+    b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, rad, d, result_size=rs, tile_size=32)
+    ref = gs.gpu_rasterize(gpu_ctx, None, None, c, col, 1 / (1 + np.exp(-gaussians.opacity)), con, b, training=False,
+                           result_size=rs, tile_size=32)
+    np.testing.assert_allclose(img, ref, rtol=0, atol=2e-6)      # float32 vs float64 sigmoid of the logits
+    assert img.max() > 0.05
