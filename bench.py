@@ -96,9 +96,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): GS_BENCH_BACKEND=gloo and
+    # GS_BENCH_SHARE_GPU=1 run every rank on cuda:0 with host-staged collectives
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    if os.environ.get("GS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local_rank)
 
     W, H, N = args.width, args.height, args.gaussians
@@ -122,14 +130,24 @@ def main():
             return image
         return gs.train_step(pipe, views, targets, grads, concurrent_views=args.concurrent_views)
 
+    trace = os.environ.get("GS_BENCH_TRACE") == "1"
+
+    def mark(what):
+        if trace:
+            print(f"[rank {rank}] {what}", file=sys.stderr, flush=True)
+
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    mark("scene ready")
     for _ in range(args.warmup):
         step()
+        mark("warmup step done")
     barrier()
+    mark("barrier passed")
     ctxs = [ctx] + ([c for c, _ in pipe.lanes(args.concurrent_views)] if args.concurrent_views > 1 else [])
     for c in ctxs:
         c.profile(True)
