@@ -20,6 +20,11 @@ class GsViewBackward(ctypes.Structure):
                 ("grad_rows", ctypes.c_void_p)]
 
 
+class GsViewPreprocess(ctypes.Structure):
+    _fields_ = [("cam", ctypes.POINTER(GsCamera))] + [(n, ctypes.c_void_p) for n in
+                ("centers", "depths", "colors", "conics", "clamped", "tiles_touched", "radii")]
+
+
 class GsError(RuntimeError):
     pass
 
@@ -42,6 +47,7 @@ SIGNATURES = {
     "gs_last_error": (ctypes.c_char_p, []),
     "gs_version": (ctypes.c_int, []),
     "gs_preprocess": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, ctypes.POINTER(GsCamera)] + [_P] * 13),
+    "gs_preprocess_batch": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _I32, ctypes.POINTER(GsViewPreprocess)]),
     "gs_bin_count": (ctypes.c_int, [_P, _I32, _P, _P, _I32, _I32, _I32, ctypes.POINTER(_I64)]),
     "gs_bin_fill": (ctypes.c_int, [_P, _I32, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P]),
     "gs_blend_forward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),

@@ -18,25 +18,28 @@ __device__ inline int clamp_to_tile(double v, double size, double tile) {
     return (int)(m / tile);
 }
 
-__global__ __launch_bounds__(256) void preprocess_kernel(
-    int N, const float *__restrict__ means, const float *__restrict__ log_scales,
-    const float *__restrict__ quats, const float *__restrict__ sh, PreCam cam,
-    float *__restrict__ centers, int32_t *__restrict__ depths, float *__restrict__ colors,
-    float *__restrict__ conics, uint8_t *__restrict__ clamped, int32_t *__restrict__ tiles_touched,
-    int32_t *__restrict__ radii, float *__restrict__ Ws, float *__restrict__ Ms,
-    float *__restrict__ Ts, float *__restrict__ cov2d, float *__restrict__ cov3d,
-    float *__restrict__ dirs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+// everything of one gaussian that depends on the view; `coef` holds its 48 SH coefficients
+struct PreOut {
+    float cx, cy, col[3], con[3];
+    uint8_t cl[3];
+    int depth, rad, rect[4];
+    double eW[6], eM[9], eT[3], eC2[3], eC3[6], eD[3];
+};
 
+template <bool EXTRAS>
+__device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, double y, double z, double q0, double q1,
+                                               double q2, double q3, const float (&ls)[3], const float (&coef)[48],
+                                               PreOut &o) {
     // outputs of a culled gaussian are all zero (the reference pre-zeroes, forward_pass.py:29-41)
-    float o_cx = 0.f, o_cy = 0.f, o_col[3] = {0.f, 0.f, 0.f}, o_con[3] = {0.f, 0.f, 0.f};
-    uint8_t o_cl[3] = {0, 0, 0};
-    int o_depth = 0, o_rad = 0, o_rect[4] = {0, 0, 0, 0};
-    double eW[6] = {0, 0, 0, 0, 0, 0}, eM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, eT[3] = {0, 0, 0},
-           eC2[3] = {0, 0, 0}, eC3[6] = {0, 0, 0, 0, 0, 0}, eD[3] = {0, 0, 0};
-
-    const double x = means[3 * i], y = means[3 * i + 1], z = means[3 * i + 2];
+    o.cx = o.cy = 0.f;
+    for (int k = 0; k < 3; k++) { o.col[k] = 0.f; o.con[k] = 0.f; o.cl[k] = 0; }
+    o.depth = 0; o.rad = 0;
+    for (int k = 0; k < 4; k++) o.rect[k] = 0;
+    if (EXTRAS) {
+        for (int k = 0; k < 6; k++) { o.eW[k] = 0; o.eC3[k] = 0; }
+        for (int k = 0; k < 9; k++) o.eM[k] = 0;
+        for (int k = 0; k < 3; k++) { o.eT[k] = 0; o.eC2[k] = 0; o.eD[k] = 0; }
+    }
 
     do {
         // :59-61  clip-space centre from WORLD coordinates (quirk Q1)
@@ -54,17 +57,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         {
             const double d = trunc(tz * 1000.0);
             if (d >= -2147483648.0 && d < 2147483648.0) {
-                o_depth = (int)d;
+                o.depth = (int)d;
             } else if (isfinite(d)) {
                 const double w = fmod(d + 2147483648.0, 4294967296.0);
-                o_depth = (int)((w < 0 ? w + 4294967296.0 : w) - 2147483648.0);
+                o.depth = (int)((w < 0 ? w + 4294967296.0 : w) - 2147483648.0);
             }
         }
 
         // :74  rotation from the normalised quaternion (w,x,y,z); as_rotation_matrix divides by
         // the squared norm once more
-        const double q0 = quats[4 * i], q1 = quats[4 * i + 1], q2 = quats[4 * i + 2],
-                     q3 = quats[4 * i + 3];
         const double qn = sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
         const double qw = q0 / qn, qx = q1 / qn, qy = q2 / qn, qz = q3 / qn;
         const double s = 2.0 / (((qw * qw + qx * qx) + qy * qy) + qz * qz);
@@ -74,9 +75,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 
         // :75  M = R @ ([[s0,1,1],[1,s1,1],[1,1,s2]] * scale_mod) (quirk Q4)
         const double sm = cam.scale_mod;
-        const double S[9] = {exp((double)log_scales[3 * i]) * sm, sm, sm,
-                             sm, exp((double)log_scales[3 * i + 1]) * sm, sm,
-                             sm, sm, exp((double)log_scales[3 * i + 2]) * sm};
+        const double S[9] = {exp((double)ls[0]) * sm, sm, sm,
+                             sm, exp((double)ls[1]) * sm, sm,
+                             sm, sm, exp((double)ls[2]) * sm};
         double M[9];
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -107,19 +108,21 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         const double c = ((W1[0] * u1[0] + W1[1] * u1[1]) + W1[2] * u1[2]) + .3;
 
         // :89-94  training extras
-        for (int k = 0; k < 3; k++) { eW[k] = W0[k]; eW[3 + k] = W1[k]; }
-        for (int k = 0; k < 9; k++) eM[k] = M[k];
-        eT[0] = tx; eT[1] = ty; eT[2] = tz;
-        eC2[0] = a; eC2[1] = b; eC2[2] = c;
-        eC3[0] = Sg[0]; eC3[1] = Sg[1]; eC3[2] = Sg[2]; eC3[3] = Sg[4]; eC3[4] = Sg[5]; eC3[5] = Sg[8];
+        if (EXTRAS) {
+            for (int k = 0; k < 3; k++) { o.eW[k] = W0[k]; o.eW[3 + k] = W1[k]; }
+            for (int k = 0; k < 9; k++) o.eM[k] = M[k];
+            o.eT[0] = tx; o.eT[1] = ty; o.eT[2] = tz;
+            o.eC2[0] = a; o.eC2[1] = b; o.eC2[2] = c;
+            o.eC3[0] = Sg[0]; o.eC3[1] = Sg[1]; o.eC3[2] = Sg[2]; o.eC3[3] = Sg[4]; o.eC3[4] = Sg[5]; o.eC3[5] = Sg[8];
+        }
 
         // :97-103  conic
         const double det = a * c - b * b;
         if (det == 0.0) break;
         const double det_inv = 1.0 / det;
-        o_con[0] = (float)(c * det_inv);
-        o_con[1] = (float)(-b * det_inv);
-        o_con[2] = (float)(a * det_inv);
+        o.con[0] = (float)(c * det_inv);
+        o.con[1] = (float)(-b * det_inv);
+        o.con[2] = (float)(a * det_inv);
 
         // :106-112  radius (quirk Q8)
         const double mid = .5 * (a + c);
@@ -133,23 +136,23 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         // the off-screen cull (quirk Q10)
         const double cx = ((ndc_x + 1.0) * cam.W - 1.0) * .5;
         const double cy = ((ndc_y + 1.0) * cam.H - 1.0) * .5;
-        o_rect[0] = clamp_to_tile(cx - radius, cam.W, cam.tile);
-        o_rect[1] = clamp_to_tile(cy - radius, cam.H, cam.tile);
-        o_rect[2] = clamp_to_tile(cx + radius + cam.tile - 1, cam.W, cam.tile);
-        o_rect[3] = clamp_to_tile(cy + radius + cam.tile - 1, cam.H, cam.tile);
+        o.rect[0] = clamp_to_tile(cx - radius, cam.W, cam.tile);
+        o.rect[1] = clamp_to_tile(cy - radius, cam.H, cam.tile);
+        o.rect[2] = clamp_to_tile(cx + radius + cam.tile - 1, cam.W, cam.tile);
+        o.rect[3] = clamp_to_tile(cy + radius + cam.tile - 1, cam.H, cam.tile);
 
         // :122-123  off-screen cull
         if (cx + radius < 0 || cx - radius > cam.W || cy + radius < 0 || cy - radius > cam.H) break;
 
-        o_rad = (int)radius;
-        o_cx = (float)cx;
-        o_cy = (float)cy;
+        o.rad = (int)radius;
+        o.cx = (float)cx;
+        o.cy = (float)cy;
 
         // :127 -> py_compute_color (:168-215)
         double dx = x - cam.cam_pos[0], dy = y - cam.cam_pos[1], dz = z - cam.cam_pos[2];
         const double dn = sqrt((dx * dx + dy * dy) + dz * dz);
         dx /= dn; dy /= dn; dz /= dn;
-        eD[0] = dx; eD[1] = dy; eD[2] = dz;
+        if (EXTRAS) { o.eD[0] = dx; o.eD[1] = dy; o.eD[2] = dz; }
         double basis[16];
         basis[0] = SH_C0;
         if (cam.degree > 0) {
@@ -171,41 +174,98 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             }
         }
         const int nb = (cam.degree + 1) * (cam.degree + 1);
-        const float4 *sh4 = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            float coef[16];
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const float4 f = sh4[ch * 4 + v];
-                coef[4 * v] = f.x; coef[4 * v + 1] = f.y; coef[4 * v + 2] = f.z; coef[4 * v + 3] = f.w;
-            }
             double r = 0.0;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (k < nb) r += basis[k] * (double)coef[k];
+                if (k < nb) r += basis[k] * (double)coef[16 * ch + k];
             r += .5;
-            if (r < 0) { r = 0; o_cl[ch] = 1; }
-            o_col[ch] = (float)r;
+            if (r < 0) { r = 0; o.cl[ch] = 1; }
+            o.col[ch] = (float)r;
         }
     } while (0);
+}
 
-    centers[2 * i] = o_cx; centers[2 * i + 1] = o_cy;
-    depths[i] = o_depth;
-    radii[i] = o_rad;
-    reinterpret_cast<int4 *>(tiles_touched)[i] = make_int4(o_rect[0], o_rect[1], o_rect[2], o_rect[3]);
+__device__ __forceinline__ void load_params(int i, const float *__restrict__ means, const float *__restrict__ log_scales,
+                                            const float *__restrict__ quats, const float *__restrict__ sh, double &x,
+                                            double &y, double &z, double (&q)[4], float (&ls)[3], float (&coef)[48]) {
+    x = means[3 * i]; y = means[3 * i + 1]; z = means[3 * i + 2];
+    for (int k = 0; k < 4; k++) q[k] = quats[4 * i + k];
+    for (int k = 0; k < 3; k++) ls[k] = log_scales[3 * i + k];
+    const float4 *sh4 = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
+#pragma unroll
+    for (int v = 0; v < 12; v++) {
+        const float4 f = sh4[v];
+        coef[4 * v] = f.x; coef[4 * v + 1] = f.y; coef[4 * v + 2] = f.z; coef[4 * v + 3] = f.w;
+    }
+}
+
+struct ViewOut {
+    float *centers, *colors, *conics;
+    int32_t *depths, *tiles_touched, *radii;
+    uint8_t *clamped;
+};
+
+__device__ __forceinline__ void store_view(int i, const ViewOut &w, const PreOut &o) {
+    w.centers[2 * i] = o.cx; w.centers[2 * i + 1] = o.cy;
+    w.depths[i] = o.depth;
+    w.radii[i] = o.rad;
+    reinterpret_cast<int4 *>(w.tiles_touched)[i] = make_int4(o.rect[0], o.rect[1], o.rect[2], o.rect[3]);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        colors[3 * i + k] = o_col[k];
-        conics[3 * i + k] = o_con[k];
-        clamped[3 * i + k] = o_cl[k];
+        w.colors[3 * i + k] = o.col[k];
+        w.conics[3 * i + k] = o.con[k];
+        w.clamped[3 * i + k] = o.cl[k];
     }
-    if (Ws) for (int k = 0; k < 6; k++) Ws[6 * i + k] = (float)eW[k];
-    if (Ms) for (int k = 0; k < 9; k++) Ms[9 * i + k] = (float)eM[k];
-    if (Ts) for (int k = 0; k < 3; k++) Ts[3 * i + k] = (float)eT[k];
-    if (cov2d) for (int k = 0; k < 3; k++) cov2d[3 * i + k] = (float)eC2[k];
-    if (cov3d) for (int k = 0; k < 6; k++) cov3d[6 * i + k] = (float)eC3[k];
-    if (dirs) for (int k = 0; k < 3; k++) dirs[3 * i + k] = (float)eD[k];
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    int N, const float *__restrict__ means, const float *__restrict__ log_scales,
+    const float *__restrict__ quats, const float *__restrict__ sh, PreCam cam, ViewOut out,
+    float *__restrict__ Ws, float *__restrict__ Ms, float *__restrict__ Ts, float *__restrict__ cov2d,
+    float *__restrict__ cov3d, float *__restrict__ dirs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double x, y, z, q[4];
+    float ls[3], coef[48];
+    load_params(i, means, log_scales, quats, sh, x, y, z, q, ls, coef);
+    PreOut o;
+    preprocess_one<true>(cam, x, y, z, q[0], q[1], q[2], q[3], ls, coef, o);
+    store_view(i, out, o);
+    if (Ws) for (int k = 0; k < 6; k++) Ws[6 * i + k] = (float)o.eW[k];
+    if (Ms) for (int k = 0; k < 9; k++) Ms[9 * i + k] = (float)o.eM[k];
+    if (Ts) for (int k = 0; k < 3; k++) Ts[3 * i + k] = (float)o.eT[k];
+    if (cov2d) for (int k = 0; k < 3; k++) cov2d[3 * i + k] = (float)o.eC2[k];
+    if (cov3d) for (int k = 0; k < 6; k++) cov3d[6 * i + k] = (float)o.eC3[k];
+    if (dirs) for (int k = 0; k < 3; k++) dirs[3 * i + k] = (float)o.eD[k];
+}
+
+// Multi-view form (no counterpart in the reference, which renders one view per iteration,
+// train.py:18-28): the 236 bytes of parameters are read once and every view of the batch is
+// projected from registers.
+constexpr int MAX_PRE_VIEWS = 8;
+struct PreBatch {
+    PreCam cam[MAX_PRE_VIEWS];
+    ViewOut out[MAX_PRE_VIEWS];
+    int n_views;
+};
+
+__global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const float *__restrict__ means,
+                                                               const float *__restrict__ log_scales,
+                                                               const float *__restrict__ quats,
+                                                               const float *__restrict__ sh, const PreBatch b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double x, y, z, q[4];
+    float ls[3], coef[48];
+    load_params(i, means, log_scales, quats, sh, x, y, z, q, ls, coef);
+#pragma unroll 1
+    for (int v = 0; v < b.n_views; v++) {
+        PreOut o;
+        preprocess_one<false>(b.cam[v], x, y, z, q[0], q[1], q[2], q[3], ls, coef, o);
+        store_view(i, b.out[v], o);
+    }
 }
 
 }  // namespace
@@ -253,9 +313,46 @@ extern "C" int gs_preprocess(gs_ctx *ctx, int32_t N, const float *means, const f
     PreCam pc;
     gs_make_precam(cam, &pc);
     GS_HIP(hipSetDevice(ctx->device));
+    ViewOut vo{centers, colors, conics, depths, tiles_touched, radii, clamped};
     { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
-                       means, log_scales, quats, sh, pc, centers, depths, colors, conics, clamped,
-                       tiles_touched, radii, Ws, Ms, Ts, cov2d, cov3d, dirs); }
+                       means, log_scales, quats, sh, pc, vo, Ws, Ms, Ts, cov2d, cov3d, dirs); }
     GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+extern "C" int gs_preprocess_batch(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                                   const float *quats, const float *sh, int32_t n_views,
+                                   const gs_view_preprocess *views) {
+    GS_REQUIRE(ctx, "gs_preprocess_batch: ctx is NULL");
+    GS_REQUIRE(N >= 0 && n_views >= 0, "gs_preprocess_batch: negative N or n_views");
+    GS_REQUIRE(n_views == 0 || views, "gs_preprocess_batch: views is NULL");
+    if (N == 0 || n_views == 0) return GS_OK;
+    GS_REQUIRE(means && log_scales && quats && sh, "gs_preprocess_batch: NULL parameter array");
+    GS_REQUIRE(((uintptr_t)sh & 15) == 0, "gs_preprocess_batch: sh must be 16-byte aligned");
+    for (int v = 0; v < n_views; v++) {
+        const gs_view_preprocess &w = views[v];
+        GS_REQUIRE(w.cam, "gs_preprocess_batch: view %d has no camera", v);
+        GS_REQUIRE(w.cam->sh_degree >= 0 && w.cam->sh_degree <= 3, "gs_preprocess_batch: sh_degree %d not in 0..3",
+                   w.cam->sh_degree);
+        GS_REQUIRE(w.cam->res_w > 0 && w.cam->res_h > 0 && w.cam->tile_size > 0 && w.cam->cam_width > 0 &&
+                       w.cam->cam_height > 0 && w.cam->fx > 0 && w.cam->fy > 0,
+                   "gs_preprocess_batch: invalid camera/frame description in view %d", v);
+        GS_REQUIRE(w.centers && w.depths && w.colors && w.conics && w.clamped && w.tiles_touched && w.radii,
+                   "gs_preprocess_batch: view %d has a NULL output", v);
+        GS_REQUIRE(((uintptr_t)w.tiles_touched & 15) == 0, "gs_preprocess_batch: tiles_touched must be 16-byte aligned");
+    }
+    GS_HIP(hipSetDevice(ctx->device));
+    for (int done = 0; done < n_views; done += MAX_PRE_VIEWS) {
+        PreBatch b;
+        b.n_views = n_views - done < MAX_PRE_VIEWS ? n_views - done : MAX_PRE_VIEWS;
+        for (int v = 0; v < b.n_views; v++) {
+            const gs_view_preprocess &w = views[done + v];
+            gs_make_precam(w.cam, &b.cam[v]);
+            b.out[v] = ViewOut{w.centers, w.colors, w.conics, w.depths, w.tiles_touched, w.radii, w.clamped};
+        }
+        { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_batch_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+                           means, log_scales, quats, sh, b); }
+        GS_HIP(hipGetLastError());
+    }
     return GS_OK;
 }

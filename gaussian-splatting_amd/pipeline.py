@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import api
-from ._lib import GsViewBackward, check
+from ._lib import GsViewBackward, GsViewPreprocess, check
 
 GRAD_FLOATS = 59   # 3 mean + 3 log-scale + 4 quaternion + 1 opacity + 48 SH
 
@@ -75,33 +75,53 @@ class SplatPipeline:
                                self.degrees)
 
     # ---- forward ------------------------------------------------------------------------
-    def forward(self, view, want_keys=False, ctx=None):
+    def _alloc_pre(self, cam):
+        dev, N, f32, i32 = self.ctx.device, self.N, torch.float32, torch.int32
+        return dict(cam=cam, centers=torch.empty((N, 2), dtype=f32, device=dev),
+                    depths=torch.empty((N,), dtype=i32, device=dev), colors=torch.empty((N, 3), dtype=f32, device=dev),
+                    conics=torch.empty((N, 3), dtype=f32, device=dev),
+                    clamped=torch.empty((N, 3), dtype=torch.uint8, device=dev),
+                    rect=torch.empty((N, 4), dtype=i32, device=dev), radii=torch.empty((N,), dtype=i32, device=dev))
+
+    def preprocess_batch(self, views, ctx=None):
+        """K1 for several views in one pass over the parameters (gs_preprocess_batch); returns one
+        record per view to hand to forward(view, pre=...)."""
         c = ctx or self.ctx
         c.sync_stream()
-        dev, N, f32, i32 = c.device, self.N, torch.float32, torch.int32
-        W, H = self.result_size
-        cam = api.make_camera(view.camera, view.camera_r, view.camera_t, self.result_size, self.tile_size,
-                              self.degrees)
-        centers = torch.empty((N, 2), dtype=f32, device=dev)
-        depths = torch.empty((N,), dtype=i32, device=dev)
-        colors = torch.empty((N, 3), dtype=f32, device=dev)
-        conics = torch.empty((N, 3), dtype=f32, device=dev)
-        clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev)
-        rect = torch.empty((N, 4), dtype=i32, device=dev)
-        radii = torch.empty((N,), dtype=i32, device=dev)
-        null = ctypes.c_void_p(0)
-        check(c.lib.gs_preprocess(c.handle, N, api._ptr(self.means), api._ptr(self.log_scales),
-                                  api._ptr(self.quats), api._ptr(self.sh), ctypes.byref(cam), api._ptr(centers),
-                                  api._ptr(depths), api._ptr(colors), api._ptr(conics), api._ptr(clamped),
-                                  api._ptr(rect), api._ptr(radii), null, null, null, null, null, null),
-              "gs_preprocess")
+        pres = [self._alloc_pre(api.make_camera(v.camera, v.camera_r, v.camera_t, self.result_size, self.tile_size,
+                                                self.degrees)) for v in views]
+        arr = (GsViewPreprocess * max(len(pres), 1))()
+        for k, p in enumerate(pres):
+            arr[k].cam = ctypes.pointer(p["cam"])
+            for name, key in (("centers", "centers"), ("depths", "depths"), ("colors", "colors"), ("conics", "conics"),
+                              ("clamped", "clamped"), ("tiles_touched", "rect"), ("radii", "radii")):
+                setattr(arr[k], name, p[key].data_ptr())
+        check(c.lib.gs_preprocess_batch(c.handle, self.N, api._ptr(self.means), api._ptr(self.log_scales),
+                                        api._ptr(self.quats), api._ptr(self.sh), len(pres), arr), "gs_preprocess_batch")
+        return pres
+
+    def forward(self, view, want_keys=False, ctx=None, pre=None):
+        c = ctx or self.ctx
+        c.sync_stream()
+        N = self.N
+        if pre is None:
+            pre = self._alloc_pre(api.make_camera(view.camera, view.camera_r, view.camera_t, self.result_size,
+                                                  self.tile_size, self.degrees))
+            null = ctypes.c_void_p(0)
+            check(c.lib.gs_preprocess(c.handle, N, api._ptr(self.means), api._ptr(self.log_scales),
+                                      api._ptr(self.quats), api._ptr(self.sh), ctypes.byref(pre["cam"]),
+                                      api._ptr(pre["centers"]), api._ptr(pre["depths"]), api._ptr(pre["colors"]),
+                                      api._ptr(pre["conics"]), api._ptr(pre["clamped"]), api._ptr(pre["rect"]),
+                                      api._ptr(pre["radii"]), null, null, null, null, null, null), "gs_preprocess")
+        cam, centers, depths, colors, conics = pre["cam"], pre["centers"], pre["depths"], pre["colors"], pre["conics"]
+        clamped, rect, radii = pre["clamped"], pre["rect"], pre["radii"]
         binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size, self.tile_size,
                                           want_keys=want_keys)
         opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
         image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
                                                       self.pixel_offset)
-        state = dict(ctx=c, cam=cam, depths=depths, centers=centers, colors=colors, conics=conics, clamped=clamped, radii=radii,
-                     opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final)
+        state = dict(ctx=c, cam=cam, depths=depths, centers=centers, colors=colors, conics=conics, clamped=clamped,
+                     radii=radii, opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final)
         self.stats = dict(D=binning.D)
         return image, state
 
@@ -237,20 +257,22 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
         # (the duplicate count D) only waits for that lane
         main = torch.cuda.current_stream(pipe.ctx.device)
         lanes = pipe.lanes(n_lanes)
+        pres = pipe.preprocess_batch([views[v] for v in mine])      # parameters read once for all views
         for _, stream in lanes:
             stream.wait_stream(main)
         for k, v in enumerate(mine):
             ctx, stream = lanes[k % n_lanes]
             with torch.cuda.stream(stream):
-                image, state = pipe.forward(views[v], ctx=ctx)
+                image, state = pipe.forward(views[v], ctx=ctx, pre=pres[k])
                 dL, _ = pipe.image_loss(image, targets[v], loss_kind, scale, losses[k:k + 1], ctx=ctx)
                 pipe.backward_rows(state, dL)
             states.append(state)
         for _, stream in lanes:
             main.wait_stream(stream)
     else:
+        pres = pipe.preprocess_batch([views[v] for v in mine])
         for k, v in enumerate(mine):
-            image, state = pipe.forward(views[v])
+            image, state = pipe.forward(views[v], pre=pres[k])
             dL, _ = pipe.image_loss(image, targets[v], loss_kind, scale, losses[k:k + 1])
             pipe.backward_rows(state, dL)
             states.append(state)

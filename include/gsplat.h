@@ -71,6 +71,19 @@ int gs_preprocess(gs_ctx *ctx, int32_t N, const float *means, const float *log_s
                   uint8_t *clamped, int32_t *tiles_touched, int32_t *radii,
                   float *Ws, float *Ms, float *Ts, float *cov2d, float *cov3d, float *dirs);
 
+/* Multi-view form of gs_preprocess (no counterpart in the reference, which projects one view per
+ * iteration, train.py:18-28): the parameters are read once and projected for every view of the
+ * batch (launches of up to 8 views); per view the outputs equal gs_preprocess's bit for bit.
+ * `views` is a HOST array; the output pointers are device pointers (no training extras). */
+typedef struct gs_view_preprocess {
+    const gs_camera *cam;
+    float *centers; int32_t *depths; float *colors; float *conics; uint8_t *clamped;
+    int32_t *tiles_touched; int32_t *radii;
+} gs_view_preprocess;
+int gs_preprocess_batch(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                        const float *quats, const float *sh, int32_t n_views,
+                        const gs_view_preprocess *views);
+
 /* Replaces match_gaus_to_tiles (rasterization.py:6-25) + kernel tile_match (setup_gpu.py:23-44)
  * + the per-tile filter and RadixSort (rasterization.py:57,66-71), in O(D) instead of
  * O(tiles*N).  Two phases so the caller owns the D-sized outputs:

@@ -518,3 +518,23 @@ def test_tile_size_32_render_path(gpu_ctx, name):
     _assert_grad(d_colors, aux["colors"].grad.numpy(), "d_colors t32", tol=2e-3)
     _assert_grad(d_conics, aux["conics"].grad.numpy(), "d_conics t32", tol=2e-3)
     _assert_grad(d_opac, p["in_opacity"].grad.numpy(), "d_opacity t32", tol=2e-3)
+
+
+def test_preprocess_batch_equals_single_view_calls(gpu_ctx):
+    """gs_preprocess_batch (10 views = two launches) gives gs_preprocess's outputs bit for bit."""
+    import torch
+    import gsplat_amd as gs
+    cam, R, t, g, rs = synth_scene(50_000, 640, 360, seed=21, fx=400.0)
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    views = []
+    for k in range(10):
+        a = 0.05 * (k - 4)
+        Rk = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        views.append(gs.View(cam, Rk, np.array([0.02 * k, -0.01 * k, 0.3 * k])))
+    pres = pipe.preprocess_batch(views)
+    for v, pre in zip(views, pres):
+        image, st = pipe.forward(v)
+        for key in ("centers", "depths", "colors", "conics", "clamped", "radii"):
+            assert torch.equal(st[key], pre[key]), key
+        image2, st2 = pipe.forward(v, pre=pre)
+        assert torch.equal(image, image2) and torch.equal(st2["binning"].vals, st["binning"].vals)
