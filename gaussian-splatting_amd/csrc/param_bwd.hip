@@ -40,8 +40,11 @@ struct BatchArgs {
     int n_views;
 };
 
+#ifndef GS_K8_WAVES
+#define GS_K8_WAVES 1
+#endif
 template <bool ROWS>
-__global__ __launch_bounds__(256) void param_bwd_kernel(
+__global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
     int N, const float *__restrict__ means, const float *__restrict__ log_scales,
     const float *__restrict__ quats, const float *__restrict__ sh, const float *__restrict__ opacity,
     int opacity_is_logit, const BatchArgs args, int accumulate, float *__restrict__ dL_dmeans,
@@ -148,49 +151,60 @@ __global__ __launch_bounds__(256) void param_bwd_kernel(
                 const double g_cr = d_a * W0[cc] * W0[r] + d_b * W0[cc] * W1[r] + d_c * W1[cc] * W1[r];
                 H[3 * r + cc] += g_rc + g_cr;
             }
-        // ---- colour -> SH coefficients and view direction -> mean (py_compute_color)
+        // ---- colour -> SH coefficients and view direction -> mean (py_compute_color).  The direction
+        // is normalised in fp64; the SH polynomial, its gradient and the 48-term sums are fp32 (an
+        // outer product and short dot products: 1e-6 relative is far inside the 1e-4 bar, at half
+        // the registers and issue cycles of fp64).
         double vx = x - cam.cam_pos[0], vy = y - cam.cam_pos[1], vz = z - cam.cam_pos[2];
         const double vn = sqrt(vx * vx + vy * vy + vz * vz);
-        const double dx = vx / vn, dy = vy / vn, dz = vz / vn;
-        double basis[16], bx[16], by[16], bz[16];
-        for (int k = 0; k < 16; k++) basis[k] = bx[k] = by[k] = bz[k] = 0.0;
-        basis[0] = SH_C0;
+        const double ddx_n = vx / vn, ddy_n = vy / vn, ddz_n = vz / vn;
+        const float dx = (float)ddx_n, dy = (float)ddy_n, dz = (float)ddz_n;
+        float basis[16], bx[16], by[16], bz[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) basis[k] = bx[k] = by[k] = bz[k] = 0.0f;
+        constexpr float C0 = (float)SH_C0, C1 = (float)SH_C1;
+        constexpr float C20 = (float)SH_C2_0, C21 = (float)SH_C2_1, C22 = (float)SH_C2_2, C23 = (float)SH_C2_3,
+                        C24 = (float)SH_C2_4;
+        constexpr float C30 = (float)SH_C3_0, C31 = (float)SH_C3_1, C32 = (float)SH_C3_2, C33 = (float)SH_C3_3,
+                        C34 = (float)SH_C3_4, C35 = (float)SH_C3_5, C36 = (float)SH_C3_6;
+        basis[0] = C0;
         if (cam.degree > 0) {
-            basis[1] = -dy * SH_C1; by[1] = -SH_C1;
-            basis[2] = dz * SH_C1;  bz[2] = SH_C1;
-            basis[3] = -dx * SH_C1; bx[3] = -SH_C1;
+            basis[1] = -dy * C1; by[1] = -C1;
+            basis[2] = dz * C1;  bz[2] = C1;
+            basis[3] = -dx * C1; bx[3] = -C1;
             if (cam.degree > 1) {
-                const double xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
-                basis[4] = SH_C2_0 * xy; bx[4] = SH_C2_0 * dy; by[4] = SH_C2_0 * dx;
-                basis[5] = SH_C2_1 * yz; by[5] = SH_C2_1 * dz; bz[5] = SH_C2_1 * dy;
-                basis[6] = SH_C2_2 * (2.0 * zz - xx - yy);
-                bx[6] = -2.0 * SH_C2_2 * dx; by[6] = -2.0 * SH_C2_2 * dy; bz[6] = 4.0 * SH_C2_2 * dz;
-                basis[7] = SH_C2_3 * xz; bx[7] = SH_C2_3 * dz; bz[7] = SH_C2_3 * dx;
-                basis[8] = SH_C2_4 * (xx - yy); bx[8] = 2.0 * SH_C2_4 * dx; by[8] = -2.0 * SH_C2_4 * dy;
+                const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+                basis[4] = C20 * xy; bx[4] = C20 * dy; by[4] = C20 * dx;
+                basis[5] = C21 * yz; by[5] = C21 * dz; bz[5] = C21 * dy;
+                basis[6] = C22 * (2.0f * zz - xx - yy);
+                bx[6] = -2.0f * C22 * dx; by[6] = -2.0f * C22 * dy; bz[6] = 4.0f * C22 * dz;
+                basis[7] = C23 * xz; bx[7] = C23 * dz; bz[7] = C23 * dx;
+                basis[8] = C24 * (xx - yy); bx[8] = 2.0f * C24 * dx; by[8] = -2.0f * C24 * dy;
                 if (cam.degree > 2) {
-                    basis[9] = SH_C3_0 * dy * (3.0 * xx - yy);
-                    bx[9] = SH_C3_0 * 6.0 * xy; by[9] = SH_C3_0 * (3.0 * xx - 3.0 * yy);
-                    basis[10] = SH_C3_1 * xy * dz;
-                    bx[10] = SH_C3_1 * yz; by[10] = SH_C3_1 * xz; bz[10] = SH_C3_1 * xy;
-                    basis[11] = SH_C3_2 * dy * (4.0 * zz - xx - yy);
-                    bx[11] = SH_C3_2 * (-2.0 * xy); by[11] = SH_C3_2 * (4.0 * zz - xx - 3.0 * yy); bz[11] = SH_C3_2 * 8.0 * yz;
-                    basis[12] = SH_C3_3 * dz * (2.0 * zz - 3.0 * xx - 3.0 * yy);
-                    bx[12] = SH_C3_3 * (-6.0 * xz); by[12] = SH_C3_3 * (-6.0 * yz); bz[12] = SH_C3_3 * (6.0 * zz - 3.0 * xx - 3.0 * yy);
-                    basis[13] = SH_C3_4 * dx * (4.0 * zz - xx - yy);
-                    bx[13] = SH_C3_4 * (4.0 * zz - 3.0 * xx - yy); by[13] = SH_C3_4 * (-2.0 * xy); bz[13] = SH_C3_4 * 8.0 * xz;
-                    basis[14] = SH_C3_5 * dz * (xx - yy);
-                    bx[14] = SH_C3_5 * 2.0 * xz; by[14] = SH_C3_5 * (-2.0 * yz); bz[14] = SH_C3_5 * (xx - yy);
-                    basis[15] = SH_C3_6 * dx * (xx - 3.0 * yy);
-                    bx[15] = SH_C3_6 * (3.0 * xx - 3.0 * yy); by[15] = SH_C3_6 * (-6.0 * xy);
+                    basis[9] = C30 * dy * (3.0f * xx - yy);
+                    bx[9] = C30 * 6.0f * xy; by[9] = C30 * (3.0f * xx - 3.0f * yy);
+                    basis[10] = C31 * xy * dz;
+                    bx[10] = C31 * yz; by[10] = C31 * xz; bz[10] = C31 * xy;
+                    basis[11] = C32 * dy * (4.0f * zz - xx - yy);
+                    bx[11] = C32 * (-2.0f * xy); by[11] = C32 * (4.0f * zz - xx - 3.0f * yy); bz[11] = C32 * 8.0f * yz;
+                    basis[12] = C33 * dz * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                    bx[12] = C33 * (-6.0f * xz); by[12] = C33 * (-6.0f * yz); bz[12] = C33 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+                    basis[13] = C34 * dx * (4.0f * zz - xx - yy);
+                    bx[13] = C34 * (4.0f * zz - 3.0f * xx - yy); by[13] = C34 * (-2.0f * xy); bz[13] = C34 * 8.0f * xz;
+                    basis[14] = C35 * dz * (xx - yy);
+                    bx[14] = C35 * 2.0f * xz; by[14] = C35 * (-2.0f * yz); bz[14] = C35 * (xx - yy);
+                    basis[15] = C36 * dx * (xx - 3.0f * yy);
+                    bx[15] = C36 * (3.0f * xx - 3.0f * yy); by[15] = C36 * (-6.0f * xy);
                 }
             }
         }
         const int nb = (cam.degree + 1) * (cam.degree + 1);
         const float4 *sh4 = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
-        double ddx = 0, ddy = 0, ddz = 0;   // dL/d(dir)
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // dL/d(dir)
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const double dcol = V.clamped[3 * i + ch] ? 0.0 : (double)in_col[ch];
+            const float dcol = V.clamped[3 * i + ch] ? 0.0f : in_col[ch];
+            float ex = 0.f, ey = 0.f, ez = 0.f;
 #pragma unroll
             for (int vv = 0; vv < 4; vv++) {
                 const float4 f = sh4[ch * 4 + vv];
@@ -199,19 +213,22 @@ __global__ __launch_bounds__(256) void param_bwd_kernel(
                 for (int e = 0; e < 4; e++) {
                     const int k = 4 * vv + e;
                     if (k < nb) {
-                        ddx += dcol * bx[k] * (double)coef[e];
-                        ddy += dcol * by[k] * (double)coef[e];
-                        ddz += dcol * bz[k] * (double)coef[e];
-                        acc_sh[ch * 16 + k] += (float)(dcol * basis[k]);
+                        ex = __builtin_fmaf(bx[k], coef[e], ex);
+                        ey = __builtin_fmaf(by[k], coef[e], ey);
+                        ez = __builtin_fmaf(bz[k], coef[e], ez);
+                        acc_sh[ch * 16 + k] = __builtin_fmaf(dcol, basis[k], acc_sh[ch * 16 + k]);
                     }
                 }
             }
+            ddx = __builtin_fmaf(dcol, ex, ddx);
+            ddy = __builtin_fmaf(dcol, ey, ddy);
+            ddz = __builtin_fmaf(dcol, ez, ddz);
         }
         // dir = v/|v|: dL/dv = (dL/ddir - dir (dir . dL/ddir)) / |v|   (dnormvdv, setup_gpu.py:256-266)
-        const double dot = dx * ddx + dy * ddy + dz * ddz;
-        g_mean[0] += (ddx - dx * dot) / vn;
-        g_mean[1] += (ddy - dy * dot) / vn;
-        g_mean[2] += (ddz - dz * dot) / vn;
+        const double dot = ddx_n * ddx + ddy_n * ddy + ddz_n * ddz;
+        g_mean[0] += ((double)ddx - ddx_n * dot) / vn;
+        g_mean[1] += ((double)ddy - ddy_n * dot) / vn;
+        g_mean[2] += ((double)ddz - ddz_n * dot) / vn;
     }
 
     if (any) {
