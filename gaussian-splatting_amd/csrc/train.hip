@@ -79,7 +79,8 @@ __global__ __launch_bounds__(LOSS_BLOCKS) void image_loss_total_kernel(const dou
 
 struct AdamGroups {
     float *param[5];        // means, log_scales, quats, opacity, sh
-    long long begin[6];     // element offsets of the groups inside the flat [N*59] buffers
+    long long begin[6];     // element offsets of the groups inside the flat buffers (multiples of 4)
+    long long count[5];     // elements in each group (3N, 3N, 4N, N, 48N)
     float lr[5];
 };
 
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(256) void adam_kernel(long long total, AdamGroups g
         const long long i = i0 + k;
         if (i >= total) break;
         while (grp < 4 && i >= gr.begin[grp + 1]) grp++;
-        float *p = gr.param[grp] + (i - gr.begin[grp]);
+        const long long e = i - gr.begin[grp];
+        if (e >= gr.count[grp]) continue;                       // alignment padding between groups
+        float *p = gr.param[grp] + e;
         float gk = g[k];
         if (!(gk == gk) || fabsf(gk) > 3.0e38f) gk = 0.0f;      // np.nan_to_num (train.py:52-55)
         if (mode == 0) {
@@ -186,8 +189,9 @@ extern "C" int gs_adam_step(gs_ctx *ctx, int32_t N, float *means, float *log_sca
     for (int k = 0; k < 5; k++) {
         gr.param[k] = ps[k];
         gr.begin[k] = off;
+        gr.count[k] = sizes[k] * (long long)N;
         gr.lr[k] = lr_host5[k];
-        off += sizes[k] * (long long)N;
+        off = (off + sizes[k] * (long long)N + 3) / 4 * 4;     // groups start at multiples of 4 floats
     }
     gr.begin[5] = off;
     const float c1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));

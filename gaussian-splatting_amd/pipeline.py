@@ -19,19 +19,33 @@ from ._lib import GsViewBackward, GsViewPreprocess, check
 GRAD_FLOATS = 59   # 3 mean + 3 log-scale + 4 quaternion + 1 opacity + 48 SH
 
 
+GROUP_WIDTHS = (3, 3, 4, 1, 48)   # means, log_scales, quats, opacity, sh
+
+
+def flat_offsets(N):
+    """Float offsets of the five parameter groups inside the flat gradient / moment buffers and the
+    total length.  Every group starts at a multiple of 4 floats (16 bytes: the kernels store
+    float4s), so for N % 4 != 0 the buffer is a few floats longer than N*59."""
+    offs, o = [], 0
+    for w in GROUP_WIDTHS:
+        offs.append(o)
+        o = (o + w * N + 3) // 4 * 4
+    return offs, o
+
+
 class FlatGrads:
-    """One contiguous fp32 buffer [N*59] with per-parameter views, so a single collective moves
-    every gradient."""
+    """One contiguous fp32 buffer (N*59 floats, plus alignment padding) with per-parameter views,
+    so a single collective moves every gradient."""
 
     def __init__(self, N, device):
         self.N = N
-        self.flat = torch.zeros(N * GRAD_FLOATS, dtype=torch.float32, device=device)
-        o = 0
-        self.means = self.flat[o:o + 3 * N].view(N, 3); o += 3 * N
-        self.log_scales = self.flat[o:o + 3 * N].view(N, 3); o += 3 * N
-        self.quats = self.flat[o:o + 4 * N].view(N, 4); o += 4 * N
-        self.opacity = self.flat[o:o + N]; o += N
-        self.sh = self.flat[o:o + 48 * N].view(N, 3, 16)
+        offs, total = flat_offsets(N)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.means = self.flat[offs[0]:offs[0] + 3 * N].view(N, 3)
+        self.log_scales = self.flat[offs[1]:offs[1] + 3 * N].view(N, 3)
+        self.quats = self.flat[offs[2]:offs[2] + 4 * N].view(N, 4)
+        self.opacity = self.flat[offs[3]:offs[3] + N]
+        self.sh = self.flat[offs[4]:offs[4] + 48 * N].view(N, 3, 16)
 
     def zero_(self):
         self.flat.zero_()
@@ -205,7 +219,7 @@ class Optimizer:
         self.pipe, self.method, self.betas, self.eps = pipe, method, betas, float(eps)
         self.lr = (ctypes.c_float * 5)(lr["center"], lr["scaling"], lr["rotation"], lr["opacity"], lr["sh"])
         self.step_count = 0
-        n = pipe.N * GRAD_FLOATS
+        n = flat_offsets(pipe.N)[1]
         dev = pipe.ctx.device
         self.m = torch.zeros(n, dtype=torch.float32, device=dev) if method == "adam" else None
         self.v = torch.zeros(n, dtype=torch.float32, device=dev) if method == "adam" else None

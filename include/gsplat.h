@@ -183,7 +183,8 @@ int gs_backward_params_batch(gs_ctx *ctx, int32_t N, const float *means, const f
  * gs_adam_step replaces the parameter update of train.py:51-56.  mode 0: Adam with bias
  * correction for `step` (1-based), one learning rate per group in the order means, log_scales,
  * quats, opacity, sh (main.py:11-17: .0008, .025, .005, .25, .0125); grad_flat / m_flat / v_flat are
- * the flat [N*59] buffers laid out in that order.  mode 1: the reference's intent,
+ * the flat buffers laid out in that order, each group (3N, 3N, 4N, N, 48N floats) starting at the
+ * next multiple of 4 floats (N*59 floats in all when N % 4 == 0).  mode 1: the reference's intent,
  * param -= lr * grad * sgd_scale (sgd_scale = the L1 loss, train.py:52-56).  Non-finite gradients
  * count as 0 (np.nan_to_num, train.py:52-55). */
 int gs_image_loss(gs_ctx *ctx, int64_t n, const float *image, const float *target, int32_t kind,

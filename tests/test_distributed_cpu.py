@@ -88,7 +88,9 @@ def test_two_ranks_equal_one_rank(tmp_path, n_views):
 def test_flat_grads_views_alias_one_buffer():
     import gsplat_amd as gs
     g = gs.FlatGrads(5, torch.device("cpu"))
-    assert g.flat.numel() == 5 * 59
+    offs, total = gs.flat_offsets(5)
+    assert g.flat.numel() == total == 300 and offs == [0, 16, 32, 52, 60]     # groups start on 16-byte boundaries
+    assert gs.flat_offsets(8) == ([0, 24, 48, 80, 88], 8 * 59)
     g.means.fill_(1); g.log_scales.fill_(2); g.quats.fill_(3); g.opacity.fill_(4); g.sh.fill_(5)
     assert g.flat.sum().item() == 5 * (3 * 1 + 3 * 2 + 4 * 3 + 4 + 48 * 5)
     g.zero_()

@@ -53,7 +53,7 @@ def test_adam_matches_torch_optim(gpu_ctx):
     grads = gs.FlatGrads(pipe.N, gpu_ctx.device)
     gen = torch.Generator().manual_seed(2)
     for step in range(4):
-        flat = torch.randn(pipe.N * 59, generator=gen) * 10.0 ** (step - 2)
+        flat = torch.randn(grads.flat.numel(), generator=gen) * 10.0 ** (step - 2)
         if step == 2:
             flat[5] = float("nan")                  # nan_to_num: counts as a zero gradient
             flat[77] = float("inf")
@@ -77,7 +77,7 @@ def test_reference_update_rule(gpu_ctx):
     pipe = gs.SplatPipeline(g, rs, ctx=gpu_ctx)
     before = [p.detach().cpu().clone() for p in _params(pipe)]
     grads = gs.FlatGrads(pipe.N, gpu_ctx.device)
-    grads.flat.copy_(torch.randn(pipe.N * 59, generator=torch.Generator().manual_seed(3)).to(gpu_ctx.device))
+    grads.flat.copy_(torch.randn(grads.flat.numel(), generator=torch.Generator().manual_seed(3)).to(gpu_ctx.device))
     gs.Optimizer(pipe, {"center": .5}, method="reference").step(grads, loss=0.25)
     lr = dict(gs.REFERENCE_LEARNING_RATES, center=.5)
     for p0, p1, gv, key in zip(before, _params(pipe), (grads.means, grads.log_scales, grads.quats, grads.opacity, grads.sh),
@@ -147,3 +147,64 @@ def test_render_entry_from_ply(gpu_ctx, tmp_path):
                            result_size=rs, tile_size=32)
     np.testing.assert_allclose(img, ref, rtol=0, atol=2e-6)      # float32 vs float64 sigmoid of the logits
     assert img.max() > 0.05
+
+
+def test_densify_clone_split_prune(gpu_ctx):
+    """Adaptive density control (3DGS paper section 5.2; no reference counterpart): counts, shapes,
+    moment remapping, determinism, and that the pipeline keeps rendering and training afterwards."""
+    import torch
+    import gsplat_amd as gs
+    W, H = 160, 112
+    cam, R, t, g, rs = synth_scene(500, W, H, seed=14, fx=120.0, log_scale=(1.5, 3.5), degree=1)
+    g.opacity[:40] = 0.001                                     # to be pruned
+    target = torch.rand(W, H, 3, generator=torch.Generator().manual_seed(0)).to(gpu_ctx.device)
+
+    def run(seed):
+        pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+        opt = gs.Optimizer(pipe, None)
+        grads = gs.FlatGrads(pipe.N, gpu_ctx.device)
+        den = gs.Densifier(pipe, opt, grad_threshold=0.0, percent_dense=0.01, scene_extent=20.0, seed=seed)
+        image, st = pipe.forward(gs.View(cam, R, t))
+        dL, _ = pipe.image_loss(image, target, "l1", 1.0)
+        pipe.backward_rows(st, dL)
+        pipe.backward_params([st], grads)
+        opt.step(grads)
+        den.accumulate([st])
+        vis = (st["radii"] > 0).cpu().numpy()
+        big = (np.exp(pipe.log_scales.cpu().numpy()) * 3.0 / H).max(axis=1) > 0.01 * 20.0
+        m_before = opt.m.clone()
+        n_before = pipe.N
+        ls_before = pipe.log_scales.cpu().numpy().copy()
+        stats = den.step()
+        return pipe, opt, stats, vis, big, m_before, n_before, ls_before
+
+    pipe, opt, stats, vis, big, m_before, n_before, ls_before = run(3)
+    # threshold 0 => every gaussian is "hot" (avg >= 0): split the big ones, clone the small ones
+    assert stats["split"] == int(big.sum()) and stats["cloned"] == int((~big).sum())
+    low = np.asarray(g.opacity) < 0.005
+    assert stats["pruned"] == int((low & ~big).sum())
+    n_keep = int((~big & ~low).sum())
+    assert stats["N"] == pipe.N == n_keep + stats["cloned"] + 2 * stats["split"]
+    assert pipe.means.shape == (pipe.N, 3) and pipe.sh.shape == (pipe.N, 3, 16) and pipe.opacity.shape == (pipe.N,)
+    assert opt.m.numel() == gs.flat_offsets(pipe.N)[1] >= pipe.N * 59
+    # kept gaussians keep their first-moment rows; new ones start at zero
+    keep_idx = np.nonzero(~big & ~low)[0]
+    np.testing.assert_array_equal(opt.m[:3 * pipe.N].view(pipe.N, 3)[:n_keep].cpu().numpy(),
+                                  m_before[:3 * n_before].view(n_before, 3)[keep_idx].cpu().numpy())
+    assert float(opt.m[:3 * pipe.N].view(pipe.N, 3)[n_keep:].abs().max()) == 0.0
+    # split children are smaller by the split factor
+    kids = pipe.log_scales[n_keep + stats["cloned"]:]
+    np.testing.assert_allclose(kids[:stats["split"]].cpu().numpy(), ls_before[big] - np.float32(np.log(1.6)), rtol=1e-6)
+    # deterministic for a fixed seed, different for another
+    # (float atomics make the gradients, hence the Adam-updated parents, differ in the last bits)
+    pipe2 = run(3)[0]
+    assert float((pipe.means - pipe2.means).abs().max()) < 1e-4
+    assert float((pipe.means - run(4)[0].means).abs().max()) > 1e-3
+    # still renders and trains with the new N
+    grads = gs.FlatGrads(pipe.N, gpu_ctx.device)
+    image, st = pipe.forward(gs.View(cam, R, t))
+    dL, loss = pipe.image_loss(image, target, "l1", 1.0)
+    pipe.backward_rows(st, dL)
+    pipe.backward_params([st], grads)
+    opt.step(grads)
+    assert bool(torch.isfinite(grads.flat).all()) and bool(torch.isfinite(pipe.means).all())
