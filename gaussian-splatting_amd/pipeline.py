@@ -235,7 +235,7 @@ class Optimizer:
               "gs_adam_step")
 
 
-def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2"):
+def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None):
     """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
@@ -291,6 +291,8 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
             pipe.backward_rows(state, dL)
             states.append(state)
     loss = losses.sum()
+    if states_hook is not None:      # e.g. Densifier.accumulate: per-view blend gradients are still alive here
+        states_hook(states)
     # one pass over the gaussians for all local views; writes (not adds) every gradient
     pipe.backward_params(states, grads, accumulate=False)
     if distributed and world > 1:

@@ -38,10 +38,13 @@ def train_model(cameras, images, point_cloud_data, learning_rates, ctx=None, que
                 iters=2000, result_size=[979, 546], t0=None, *, views_per_step=8, image_loader=None,
                 image_dir="./input/images", output_dir="output/test_run", method="adam", loss="l1",
                 subset_fraction=.2, seed=None, gaussians=None, save_images_every=50, checkpoint_every=100,
-                concurrent_views=3, log=print):
+                concurrent_views=3, log=print, densify_every=None, densify_from=500, densify_until=15000,
+                densify_options=None):
     """train.py:12-64.  cameras / images / point_cloud_data: a COLMAP model (io.read_model or the
     reference's reader); learning_rates: the dict of main.py:11-17 (keys center, scaling, opacity,
-    rotation, sh).  Returns (gaussians, history of per-iteration mean losses)."""
+    rotation, sh).  densify_every=k runs the Densifier (clone / split / prune; no reference
+    counterpart) every k iterations between densify_from and densify_until.  Returns (gaussians,
+    history of per-iteration mean losses)."""
     t0 = time.perf_counter() if t0 is None else t0
     rnd = random.Random(seed)
     if gaussians is None:
@@ -56,6 +59,10 @@ def train_model(cameras, images, point_cloud_data, learning_rates, ctx=None, que
     dev = pipe.ctx.device
     grads = FlatGrads(pipe.N, dev)
     opt = Optimizer(pipe, learning_rates, method=method)
+    den = None
+    if densify_every:
+        from .densify import Densifier
+        den = Densifier(pipe, opt, seed=0 if seed is None else seed, **(densify_options or {}))
     target_cache = {}
     history = []
     log("setup complete in {time}s".format(time=time.perf_counter() - t0))
@@ -73,10 +80,15 @@ def train_model(cameras, images, point_cloud_data, learning_rates, ctx=None, que
                 target_cache[src.id] = torch.from_numpy(np.ascontiguousarray(loader(src), dtype=np.float32)).to(dev)
             targets.append(target_cache[src.id])
         loss_sum, n_local = train_step(pipe, views, targets, grads, loss_scale=1.0 / views_per_step,
-                                       concurrent_views=concurrent_views, loss_kind=loss)
+                                       concurrent_views=concurrent_views, loss_kind=loss,
+                                       states_hook=den.accumulate if den else None)
         mean_loss = float(loss_sum.item()) / max(n_local, 1)
         opt.step(grads, loss=mean_loss)                                           # train.py:51-56
         history.append(mean_loss)
+        if den and densify_from <= i <= densify_until and i > 0 and i % densify_every == 0:
+            stats = den.step()
+            grads = FlatGrads(pipe.N, dev)
+            log("densify: {s}".format(s=stats))
         log("pass {iter} completed in {time}s\nloss = {loss}\n-----------------------".format(
             time=time.perf_counter() - t1, iter=i, loss=mean_loss))
         if output_dir and save_images_every and i % save_images_every == 0:       # train.py:61-62

@@ -208,3 +208,27 @@ def test_densify_clone_split_prune(gpu_ctx):
     pipe.backward_params([st], grads)
     opt.step(grads)
     assert bool(torch.isfinite(grads.flat).all()) and bool(torch.isfinite(pipe.means).all())
+
+
+def test_train_model_with_densification(gpu_ctx):
+    """configs[3] in miniature: the gaussian count grows during training and the loop keeps going."""
+    import gsplat_amd as gs
+    W, H = 128, 96
+    cam, R, t, g, rs = synth_scene(300, W, H, seed=18, fx=100.0, log_scale=(2.0, 3.2), degree=0)
+    Camera = collections.namedtuple("Camera", ["id", "model", "width", "height", "params"])
+    Image = collections.namedtuple("Image", ["id", "qvec", "tvec", "camera_id", "name"])
+    cameras = {1: Camera(1, "PINHOLE", W, H, np.array(cam.params))}
+    images = {k: Image(k, np.array([1.0, 0, 0, 0]), np.array([0.01 * k, 0, 0]), 1, f"{k}.jpg") for k in range(1, 6)}
+    truth = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    loader = lambda src: truth.forward(gs.View(cameras[1], np.eye(3), src.tvec))[0].cpu().numpy()
+    start = types.SimpleNamespace(center=g.center[:150], scaling=g.scaling[:150], rotation=g.rotation[:150],
+                                  spherical_harmonics=g.spherical_harmonics[:150], opacity=g.opacity[:150], degrees=0)
+    msgs = []
+    out, hist = gs.train_model(cameras, images, None, gs.REFERENCE_LEARNING_RATES, gpu_ctx, None, None, iters=12,
+                               result_size=rs, views_per_step=2, image_loader=loader, output_dir=None, subset_fraction=1.0,
+                               seed=2, gaussians=start, concurrent_views=2, log=lambda m: msgs.append(m),
+                               densify_every=5, densify_from=1,
+                               densify_options=dict(grad_threshold=1e-7, scene_extent=30.0, max_gaussians=400))
+    assert len(hist) == 13 and np.all(np.isfinite(hist))
+    assert sum("densify" in m for m in msgs) == 2
+    assert 150 < len(out.center) <= 400
