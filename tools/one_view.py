@@ -15,9 +15,12 @@ views = make_views(gs, cam, 8)
 grads = gs.FlatGrads(N, ctx.device)
 target = torch.rand(W, H, 3, device=ctx.device)
 states = []
-for v in range(int(os.environ.get("GS_VIEWS", 2))):
-    image, st = pipe.forward(views[v])
-    pipe.backward_rows(st, (image - target) * 1e-6)
+n = int(os.environ.get("GS_VIEWS", 2))
+pres = pipe.preprocess_batch(views[:n])
+for v in range(n):
+    image, st = pipe.forward(views[v], pre=pres[v])
+    dL, _ = pipe.image_loss(image, target, "l2", 1.0)
+    pipe.backward_rows(st, dL)
     states.append(st)
 pipe.backward_params(states, grads)
 torch.cuda.synchronize()
