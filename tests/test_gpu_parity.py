@@ -538,3 +538,68 @@ def test_preprocess_batch_equals_single_view_calls(gpu_ctx):
             assert torch.equal(st[key], pre[key]), key
         image2, st2 = pipe.forward(v, pre=pre)
         assert torch.equal(image, image2) and torch.equal(st2["binning"].vals, st["binning"].vals)
+
+
+def test_binning_randomised_against_oracle(gpu_ctx):
+    """40 random (N, frame, tile size, depth range) cases incl. degenerate rects, rects outside the grid,
+    zero and wrapped (negative) depths, heavy ties and single-tile frames: keys, values and ranges bit-exact
+    against the tile_match + filter + stable-sort restatement."""
+    import gsplat_amd as gs
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        N = int(rng.choice([1, 2, 63, 64, 65, 255, 1000, 4097, 20000]))
+        ts = int(rng.choice([8, 16, 32, 64]))
+        W, H = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        tx_n, ty_n = -(-W // ts), -(-H // ts)
+        x0 = rng.integers(-2, tx_n + 2, N); y0 = rng.integers(-2, ty_n + 2, N)
+        x1 = x0 + rng.integers(-1, 6, N); y1 = y0 + rng.integers(-1, 6, N)
+        tt = np.stack([np.stack([x0, y0], 1), np.stack([x1, y1], 1)], 1).astype(np.int32)
+        kind = case % 4
+        if kind == 0:
+            dep = rng.integers(0, 40, N)                       # heavy ties, some zeros (filtered)
+        elif kind == 1:
+            dep = rng.integers(2000, 60000, N)                 # 2 depth-sort passes
+        elif kind == 2:
+            dep = rng.integers(0, 2**24, N)                    # 3 passes
+        else:
+            dep = rng.integers(-2**31, 2**31, N)               # wrapped keys: full 32 bits
+        dep = dep.astype(np.int32)
+        b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, np.ones(N), dep, result_size=[W, H], tile_size=ts)
+        keys, vals, ranges = ref_np.bin_duplicates(tt, dep, [W, H], ts)
+        what = f"case {case}: N={N} {W}x{H} tile {ts} kind {kind}"
+        assert b.D == len(keys), what
+        if b.D:
+            assert np.array_equal(b.keys.cpu().numpy().view(np.uint64), keys), what
+            assert np.array_equal(b.vals.cpu().numpy(), vals), what
+        assert np.array_equal(b.ranges.cpu().numpy(), ranges), what
+
+
+def test_preprocess_edge_cases_vs_oracle(gpu_ctx):
+    """Near-plane boundary (view z exactly 2 is culled, forward_pass.py:65), NaN and negative z, a depth key
+    that wraps int32 (z*1000 > 2^31, forward_pass.py:70-71), huge and tiny scales, off-screen centres,
+    degenerate quaternion scale: integer outputs bit-exact against the oracle restatement."""
+    import gsplat_amd as gs
+    cam, R, t, g, rs = synth_scene(64, 640, 360, seed=33, fx=400.0)
+    c = np.array(g.center, dtype=np.float32)
+    s = np.array(g.scaling, dtype=np.float32)
+    q = np.array(g.rotation, dtype=np.float32)
+    c[0, 2] = 2.0; c[1, 2] = np.float32(2.0000002); c[2, 2] = -5.0; c[3, 2] = np.nan; c[4, 2] = 1.9999999
+    c[5] = [100.0, 50.0, 3.0e6]; c[6] = [0.0, 0.0, 2.2e6]            # int(z*1000) beyond int32
+    c[7] = [500.0, 0.0, 5.0]; c[8] = [0.0, -400.0, 5.0]              # far off screen
+    s[9] = 10.0; s[10] = -20.0; s[11] = [8.0, -8.0, 0.0]
+    q[12] = [1e-3, 0, 0, 0]; q[13] = [0, 0, 0, 50.0]                  # normalised by the kernel and the reference
+    c[14, 0] = np.inf
+    g.center, g.scaling, g.rotation = c, s, q
+    out = gs.forward_pass(gpu_ctx, None, None, cam, R, t, g, result_size=rs, tile_size=16, training=True)
+    with np.errstate(all="ignore"):
+        o = ref_np.preprocess(c, s, q, np.float32(g.spherical_harmonics), 3, cam.params[0], cam.params[1], cam.width,
+                              cam.height, R, t, rs, 16)
+    names = ["centers", "depths", "colors", "conics", "clamped", "tiles_touched", "radii"]
+    for n, got in zip(names, out[:7]):
+        if n in ("depths", "tiles_touched", "radii", "clamped"):
+            assert np.array_equal(got, o[n]), (n, np.nonzero(np.asarray(got != o[n]).reshape(64, -1).any(1))[0])
+        else:
+            np.testing.assert_allclose(got, o[n], rtol=3e-6, atol=1e-5, err_msg=n)
+    assert out[6][0] == 0 and out[6][2] == 0 and out[6][3] == 0 and out[6][4] == 0      # culled: radius 0
+    assert out[1][1] == 2000 and out[1][0] == 0        # z = 2.0000002 passes the near cull, z = 2 does not
+    assert out[1][5] != 0 and out[1][6] != 0          # wrapped, not zero
