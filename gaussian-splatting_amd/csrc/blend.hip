@@ -344,10 +344,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float TAU_MARGIN = 0.02f;    // log2 units: 1.4 % in alpha, far above fp32 error
 
+// one 64-byte record per gaussian, so that staging an entry touches ONE cache line:
+//   [0] geo = cx, cy, opacity, tau
+//   [1] con = a', b', c', 0   (log2-scaled: power2 = a' dx^2 + b' dx dy + c' dy^2)
+//   [2] rgb = r, g, b, 0      [3] zero
 struct QuadArgs {
-    const float4 *geo;    // cx, cy, opacity, tau
-    const float4 *con;    // a', b', c', 0   (log2-scaled: power2 = a' dx^2 + b' dx dy + c' dy^2)
-    const float4 *rgb;
+    const float4 *rec;
     const int32_t *vals;
     const int2 *ranges;
     float bg[3];
@@ -356,20 +358,26 @@ struct QuadArgs {
     float pixel_offset;
 };
 
+// four threads per gaussian, one float4 of the record each: stores are fully coalesced
 __global__ __launch_bounds__(256) void pack_kernel(int N, const float2 *__restrict__ centers,
                                                    const float *__restrict__ colors,
                                                    const float *__restrict__ opacities,
-                                                   const float *__restrict__ conics, float4 *__restrict__ geo,
-                                                   float4 *__restrict__ con, float4 *__restrict__ rgb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                   const float *__restrict__ conics, float4 *__restrict__ rec) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 2, part = t & 3;
     if (i >= N) return;
-    const float2 c = centers[i];
-    const float o = opacities[i];
-    const float tau = (o > 0.0f) ? (__log2f(ALPHA_MIN / o) - TAU_MARGIN) : 1e30f;
-    geo[i] = make_float4(c.x, c.y, o, tau);
-    con[i] = make_float4(-0.5f * LOG2E * conics[3 * i], -LOG2E * conics[3 * i + 1],
-                         -0.5f * LOG2E * conics[3 * i + 2], 0.0f);
-    rgb[i] = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.0f);
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (part == 0) {
+        const float2 c = centers[i];
+        const float o = opacities[i];
+        const float tau = (o > 0.0f) ? (__log2f(ALPHA_MIN / o) - TAU_MARGIN) : 1e30f;
+        v = make_float4(c.x, c.y, o, tau);
+    } else if (part == 1) {
+        v = make_float4(-0.5f * LOG2E * conics[3 * i], -LOG2E * conics[3 * i + 1], -0.5f * LOG2E * conics[3 * i + 2], 0.0f);
+    } else if (part == 2) {
+        v = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.0f);
+    }
+    rec[t] = v;
 }
 
 // max over the tile's pixel box of power2 >= tau ?  u = cx - x in [ulo,uhi], v likewise.
@@ -483,8 +491,8 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
         int g = 0;
         if (i < len) {
             g = a.vals[rg.x + i];
-            geo = a.geo[g];
-            con = a.con[g];
+            geo = a.rec[(size_t)g * 4];
+            con = a.rec[(size_t)g * 4 + 1];
             keep = tile_may_contribute(geo, con, xlo, xhi, ylo, yhi);
         }
         const unsigned long long m = __ballot(keep);
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
             con.w = __int_as_float(i);
             s_geo[pos] = geo;
             s_con[pos] = con;
-            s_rgb[pos] = a.rgb[g];
+            s_rgb[pos] = a.rec[(size_t)g * 4 + 2];
         }
         wave_lds_fence();
 
@@ -632,15 +640,15 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
         int g = 0;
         if (i < max_end) {
             g = a.vals[rg.x + i];
-            geo = a.geo[g];
-            con = a.con[g];
+            geo = a.rec[(size_t)g * 4];
+            con = a.rec[(size_t)g * 4 + 1];
             keep = tile_may_contribute(geo, con, xlo, xhi, ylo, yhi);
         }
         const unsigned long long m = __ballot(keep);
         const int n = __popcll(m);
         if (keep) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
-            float4 rgb = a.rgb[g];
+            float4 rgb = a.rec[(size_t)g * 4 + 2];
             con.w = __int_as_float(i);
             rgb.w = __int_as_float(g);
             s_geo[pos] = geo;
@@ -765,21 +773,19 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(int N, const float *__
 // reuse = the caller is gs_blend_backward*: it must be given the arrays of the forward call whose
 // n_contrib/t_final it consumes, so the records packed by that forward call are still valid.
 int fill_quad(QuadArgs &q, const BlendArgs &a, gs_ctx *ctx, int32_t N, bool reuse = false) {
-    const size_t n16 = ((size_t)(N > 0 ? N : 1) * sizeof(float4) + 255) & ~(size_t)255;
-    int rc = gs_buf_reserve(ctx, &ctx->packed, 3 * n16);
+    int rc = gs_buf_reserve(ctx, &ctx->packed, (size_t)(N > 0 ? N : 1) * 64);
     if (rc) return rc;
-    char *base = (char *)ctx->packed.p;
-    float4 *geo = (float4 *)base, *con = (float4 *)(base + n16), *rgb = (float4 *)(base + 2 * n16);
+    float4 *rec = (float4 *)ctx->packed.p;
     const void *key[4] = {a.centers, a.colors, a.opacities, a.conics};
     const bool cached = reuse && ctx->packed_N == N && memcmp(key, ctx->packed_key, sizeof key) == 0;
     memcpy(ctx->packed_key, key, sizeof key);
     ctx->packed_N = N;
     if (N > 0 && !cached) {
         gs_prof_scope prof_(ctx, GS_K_PACK);
-        hipLaunchKernelGGL(pack_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, a.centers, a.colors,
-                           a.opacities, a.conics, geo, con, rgb);
+        hipLaunchKernelGGL(pack_kernel, dim3(gs_div_up(N, 64)), dim3(256), 0, ctx->stream, N, a.centers, a.colors,
+                           a.opacities, a.conics, rec);
     }
-    q.geo = geo; q.con = con; q.rgb = rgb; q.vals = a.vals; q.ranges = a.ranges;
+    q.rec = rec; q.vals = a.vals; q.ranges = a.ranges;
     q.bg[0] = a.bg[0]; q.bg[1] = a.bg[1]; q.bg[2] = a.bg[2];
     q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
     q.list_tiles_y = a.list_tiles_y; q.shift = a.shift;

@@ -56,7 +56,7 @@ struct gs_ctx {
     gs_buf vals_tmp;     // i32[D]
     gs_buf radix_table;  // u32[256] digit totals + u32[256][blocks] per-block digit counts
     // blend workspace
-    gs_buf packed;       // float4[3][N] packed per-gaussian blend attributes
+    gs_buf packed;       // float4[N][4] 64-byte per-gaussian blend records
     gs_buf grad_rows;    // float[N][16] 64-byte gradient rows for blend backward
     gs_buf tile_scratch; // rasterize_tile shim staging
     gs_buf loss_partials; // f64[1024] per-block loss sums

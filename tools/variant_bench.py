@@ -18,6 +18,7 @@ def build(specs):
     for spec in specs:
         name, _, flags = spec.partition(":")
         flags = [f for f in flags.split(",") if f]
+        # same flags as gaussian-splatting_amd/build.py (-ffp-contract=off applies to every file here: timing only)
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-slp-vectorize",
                "-shared", "-o", lib_path(name)] + flags + [os.path.join(PKG, "csrc", s) for s in SRCS]
         procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -56,7 +57,8 @@ def run_one(name):
         pipe.backward_params(states, grads)
     prof = ctx.read_profile()
     out = {k: round(v[0] / v[1], 4) for k, v in prof.items() if v[1]}
-    print(name, {k: out[k] for k in ("blend_forward", "blend_backward", "param_backward", "bin_sort", "preprocess") if k in out},
+    print(name, {k: out[k] for k in ("blend_forward", "blend_backward", "blend_pack", "param_backward", "bin_sort", "bin_depth_sort",
+                                       "bin_duplicate", "preprocess") if k in out},
           "checksum %.6e %.6e" % (image.double().sum().item(), grads.flat.double().abs().sum().item()), flush=True)
 
 
