@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--views", type=int, default=0, help="fixed GLOBAL batch instead (strong scaling; needs --views-per-rank 0)")
     ap.add_argument("--log-scale", type=float, nargs=2, default=(1.0, 3.0))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k1-first", type=int, default=0, help="views in the first preprocess launch (0: one per lane)")
+    ap.add_argument("--k8-tail", type=int, default=1,
+                    help="views left to the final parameter-backward launch (the rest start early on the main stream; 0: one launch)")
     ap.add_argument("--concurrent-views", type=int, default=3, help="local views in flight on separate streams")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: single-view forward render")
     return ap.parse_args()
@@ -128,7 +131,8 @@ def main():
         if args.forward_only:
             image, _ = pipe.forward(views[0])
             return image
-        return gs.train_step(pipe, views, targets, grads, concurrent_views=args.concurrent_views)
+        return gs.train_step(pipe, views, targets, grads, concurrent_views=args.concurrent_views,
+                             k8_tail=args.k8_tail, k1_first=args.k1_first)
 
     trace = os.environ.get("GS_BENCH_TRACE") == "1"
 

@@ -175,10 +175,10 @@ class SplatPipeline:
         state["rows"] = rows
         return rows
 
-    def backward_params(self, states, grads, accumulate=False):
+    def backward_params(self, states, grads, accumulate=False, ctx=None):
         """K8 over every view in `states` at once (each must have been through backward_rows):
         parameters are read once and the gradients written (or added) once."""
-        c = self.ctx
+        c = ctx or self.ctx
         c.sync_stream()
         views = (GsViewBackward * max(len(states), 1))()
         for k, st in enumerate(states):
@@ -235,12 +235,14 @@ class Optimizer:
               "gs_adam_step")
 
 
-def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None):
+def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,
+               k8_tail=1, k1_first=None):
     """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
     formed together with dL/dimage by the fused native kernel.  concurrent_views > 1 renders that
-    many local views at a time on separate streams.  Returns (sum of local losses as a
+    many local views at a time on separate streams; the parameter backward of all but the last
+    k8_tail views then starts early on the main stream (0: one launch at the end).  Returns (sum of local losses as a
     device scalar, number of local views)."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -266,21 +268,40 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
             dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
         return loss, len(mine)
     losses = torch.zeros(max(len(mine), 1), dtype=torch.float32, device=pipe.ctx.device)
+    early = 0
     if n_lanes > 1:
         # independent views alternate between lanes (stream + workspace each); a lane's host sync
-        # (the duplicate count D) only waits for that lane
+        # (the duplicate count D) only waits for that lane.  The HBM-bound K1 of the later views and
+        # the latency-bound K8 of the earlier ones run on the main stream under the VALU-bound blend
+        # kernels of the other views.
         main = torch.cuda.current_stream(pipe.ctx.device)
-        lanes = pipe.lanes(n_lanes)
-        pres = pipe.preprocess_batch([views[v] for v in mine])      # parameters read once for all views
+        lanes = pipe.lanes(n_lanes)          # main + lanes <= the 4 hardware queues of a process
+        first = min(k1_first or n_lanes, len(mine))
+        early = len(mine) - k8_tail if (k8_tail and len(mine) - k8_tail >= 2) else 0
+        pres = pipe.preprocess_batch([views[v] for v in mine[:first]])
         for _, stream in lanes:
             stream.wait_stream(main)
+        pre_ready = None
+        if len(mine) > first:
+            pres += pipe.preprocess_batch([views[v] for v in mine[first:]])
+            pre_ready = main.record_event()
+        done = []
         for k, v in enumerate(mine):
             ctx, stream = lanes[k % n_lanes]
             with torch.cuda.stream(stream):
+                if k >= first:
+                    stream.wait_event(pre_ready)
                 image, state = pipe.forward(views[v], ctx=ctx, pre=pres[k])
                 dL, _ = pipe.image_loss(image, targets[v], loss_kind, scale, losses[k:k + 1], ctx=ctx)
                 pipe.backward_rows(state, dL)
+                done.append(stream.record_event())
             states.append(state)
+            if k + 1 == early and states_hook is None:
+                for e in done:
+                    main.wait_event(e)
+                pipe.backward_params(states[:early], grads, accumulate=False)
+        if states_hook is not None:
+            early = 0
         for _, stream in lanes:
             main.wait_stream(stream)
     else:
@@ -294,7 +315,7 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     if states_hook is not None:      # e.g. Densifier.accumulate: per-view blend gradients are still alive here
         states_hook(states)
     # one pass over the gaussians for all local views; writes (not adds) every gradient
-    pipe.backward_params(states, grads, accumulate=False)
+    pipe.backward_params(states[early:], grads, accumulate=early > 0)
     if distributed and world > 1:
         dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
     return loss, len(mine)
