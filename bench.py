@@ -45,9 +45,9 @@ def parse():
     ap.add_argument("--log-scale", type=float, nargs=2, default=(1.0, 3.0))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k1-first", type=int, default=0, help="views in the first preprocess launch (0: one per lane)")
-    ap.add_argument("--k8-tail", type=int, default=1,
+    ap.add_argument("--k8-tail", type=int, default=None,
                     help="views left to the final parameter-backward launch (the rest start early on the main stream; 0: one launch)")
-    ap.add_argument("--concurrent-views", type=int, default=3, help="local views in flight on separate streams")
+    ap.add_argument("--concurrent-views", type=int, default=4, help="local views in flight on separate streams")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: single-view forward render")
     return ap.parse_args()
 
@@ -152,7 +152,7 @@ def main():
         mark("warmup step done")
     barrier()
     mark("barrier passed")
-    ctxs = [ctx] + ([c for c, _ in pipe.lanes(args.concurrent_views)] if args.concurrent_views > 1 else [])
+    ctxs = [ctx] + ([c for c, _ in pipe.lanes(min(args.concurrent_views, 4) - (1 if args.concurrent_views > 3 else 0))] if args.concurrent_views > 1 else [])
     for c in ctxs:
         c.profile(True)
         c.read_profile()

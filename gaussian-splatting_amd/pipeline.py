@@ -236,13 +236,14 @@ class Optimizer:
 
 
 def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,
-               k8_tail=1, k1_first=None):
+               k8_tail=None, k1_first=None):
     """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
     formed together with dL/dimage by the fused native kernel.  concurrent_views > 1 renders that
-    many local views at a time on separate streams; the parameter backward of all but the last
-    k8_tail views then starts early on the main stream (0: one launch at the end).  Returns (sum of local losses as a
+    many local views at a time on separate streams (the 4th is the main stream); with fewer, the
+    parameter backward of all but the last k8_tail views starts early on the idle main stream
+    (0: one launch at the end; None: 1 when the main stream renders no view).  Returns (sum of local losses as a
     device scalar, number of local views)."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -275,7 +276,13 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
         # the latency-bound K8 of the earlier ones run on the main stream under the VALU-bound blend
         # kernels of the other views.
         main = torch.cuda.current_stream(pipe.ctx.device)
-        lanes = pipe.lanes(n_lanes)          # main + lanes <= the 4 hardware queues of a process
+        # a process has 4 hardware queues: up to 3 side lanes, and the main stream is the 4th lane
+        lanes = pipe.lanes(min(n_lanes, 3))
+        main_is_lane = n_lanes > 3
+        if main_is_lane:
+            lanes = pipe.lanes(n_lanes - 1) + [(pipe.ctx, main)]
+        if k8_tail is None:
+            k8_tail = 0 if main_is_lane else 1
         first = min(k1_first or n_lanes, len(mine))
         early = len(mine) - k8_tail if (k8_tail and len(mine) - k8_tail >= 2) else 0
         pres = pipe.preprocess_batch([views[v] for v in mine[:first]])

@@ -38,7 +38,7 @@ def train_model(cameras, images, point_cloud_data, learning_rates, ctx=None, que
                 iters=2000, result_size=[979, 546], t0=None, *, views_per_step=8, image_loader=None,
                 image_dir="./input/images", output_dir="output/test_run", method="adam", loss="l1",
                 subset_fraction=.2, seed=None, gaussians=None, save_images_every=50, checkpoint_every=100,
-                concurrent_views=3, log=print, densify_every=None, densify_from=500, densify_until=15000,
+                concurrent_views=4, log=print, densify_every=None, densify_from=500, densify_until=15000,
                 densify_options=None):
     """train.py:12-64.  cameras / images / point_cloud_data: a COLMAP model (io.read_model or the
     reference's reader); learning_rates: the dict of main.py:11-17 (keys center, scaling, opacity,
