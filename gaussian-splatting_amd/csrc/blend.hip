@@ -406,6 +406,19 @@ __device__ __forceinline__ bool tile_may_contribute(const float4 geo, const floa
     return !(-qmin * 0.999f + 1e-4f < geo.w);
 }
 
+// bit k set: the gaussian may reach alpha >= 1/255 somewhere in 8x8 quadrant k of the tile
+// (k>>1: x half, k&1: y half; the quadrant's pixel box spans 7 pixels each way).  Evaluated once per
+// staged entry by ONE lane, so that the 64 lanes never evaluate a quadrant the gaussian misses.
+__device__ __forceinline__ unsigned quad_mask(const float4 geo, const float4 con, float xlo, float ylo) {
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float x0 = xlo + (float)(8 * (k >> 1)), y0 = ylo + (float)(8 * (k & 1));
+        m |= tile_may_contribute(geo, con, x0, x0 + 7.0f, y0, y0 + 7.0f) ? (1u << k) : 0u;
+    }
+    return m;
+}
+
 // Four tiles per 256-thread workgroup, one wave64 each, with wave-private LDS and no workgroup
 // barrier: a CU holds at most 16 workgroups, so single-wave workgroups would cap occupancy at 4 waves
 // per SIMD; four independent waves per workgroup reach 8.  LDS operations of one wave execute in
@@ -452,12 +465,14 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
     __shared__ float4 s_geo_[QUAD_WAVES][64];
     __shared__ float4 s_con_[QUAD_WAVES][64];   // .w = original list index (bits)
     __shared__ float4 s_rgb_[QUAD_WAVES][64];
+    __shared__ unsigned s_qm_[QUAD_WAVES][64];
 
     const int wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * QUAD_WAVES + wv;
     if (tile >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
     GS_STAMP_BEGIN();
     float4 *s_geo = s_geo_[wv], *s_con = s_con_[wv], *s_rgb = s_rgb_[wv];
+    unsigned *s_qm = s_qm_[wv];
     const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
     const int lane = threadIdx.x & 63;
     const int qy = lane & 7, qx = lane >> 3;
@@ -465,78 +480,84 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
     const float off = a.pixel_offset;
     const float fx0 = (float)(X0 + qx) - off, fx1 = fx0 + 8.0f;
     const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
-    const float xlo = (float)X0 - off, xhi = xlo + 15.0f, ylo = (float)Y0 - off, yhi = ylo + 15.0f;
+    const float xlo = (float)X0 - off, ylo = (float)Y0 - off;
     const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
     const int len = rg.y - rg.x;
 
-    float T[4], C[4][3];
+    // Per pixel: T (running transmittance; 0 once the pixel is finished, so later entries add
+    // nothing without a per-lane "done" test), thr (the break threshold of rasterize.c:118; 0 once
+    // finished, so a finished pixel cannot break again), Tfin (the transmittance to report).
+    float T[4], thr[4], Tfin[4], C[4][3];
     int last[4];
-    bool done[4], broke[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int px = X0 + qx + 8 * (k >> 1), py = Y0 + qy + 8 * (k & 1);
-        T[k] = 1.0f;
+        const bool inside = px < a.W && py < a.H;
+        T[k] = inside ? 1.0f : 0.0f;
+        thr[k] = inside ? T_MIN : 0.0f;
+        Tfin[k] = 1.0f;
         C[k][0] = C[k][1] = C[k][2] = 0.0f;
         last[k] = len;
-        broke[k] = false;
-        done[k] = !(px < a.W && py < a.H);
     }
 
     for (int base = 0; base < len; base += 64) {
-        if (wave_all(done[0] && done[1] && done[2] && done[3])) break;
+        // quadrants that still have an unfinished pixel (wave-uniform, refreshed per batch)
+        bool alive[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) alive[k] = wave_any(thr[k] != 0.0f);
+        if (!(alive[0] || alive[1] || alive[2] || alive[3])) break;
         wave_lds_fence();                    // the previous batch's reads are complete
         const int i = base + lane;
-        bool keep = false;
+        unsigned qm = 0;
         float4 geo, con;
         int g = 0;
         if (i < len) {
             g = a.vals[rg.x + i];
             geo = a.rec[(size_t)g * 4];
             con = a.rec[(size_t)g * 4 + 1];
-            keep = tile_may_contribute(geo, con, xlo, xhi, ylo, yhi);
+            qm = quad_mask(geo, con, xlo, ylo);
         }
-        const unsigned long long m = __ballot(keep);
+        const unsigned long long m = __ballot(qm != 0u);
         const int n = __popcll(m);
-        if (keep) {
+        if (qm != 0u) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
             con.w = __int_as_float(i);
             s_geo[pos] = geo;
             s_con[pos] = con;
             s_rgb[pos] = a.rec[(size_t)g * 4 + 2];
+            s_qm[pos] = qm;
         }
         wave_lds_fence();
+        // live[k]: bitmap over the compacted entries that may touch quadrant k (scalar registers)
+        const unsigned myq = lane < n ? s_qm[lane] : 0u;
+        unsigned long long live[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) live[k] = alive[k] ? __ballot((myq >> k) & 1u) : 0ull;
 
-        for (int j = 0; j < n; j++) {
+        for (unsigned long long rem = live[0] | live[1] | live[2] | live[3]; rem != 0ull; rem &= rem - 1ull) {
+            const int j = __builtin_ctzll(rem);
             const float4 ge = s_geo[j];
             const float4 co = s_con[j];
-            const float dx0 = ge.x - fx0, dx1 = ge.x - fx1, dy0 = ge.y - fy0, dy1 = ge.y - fy1;
-            const float adx0 = co.x * dx0, adx1 = co.x * dx1;
-            const float cyy0 = co.z * dy0 * dy0, cyy1 = co.z * dy1 * dy1;
-            float p[4];
-            p[0] = __builtin_fmaf(dx0, __builtin_fmaf(co.y, dy0, adx0), cyy0);
-            p[1] = __builtin_fmaf(dx0, __builtin_fmaf(co.y, dy1, adx0), cyy1);
-            p[2] = __builtin_fmaf(dx1, __builtin_fmaf(co.y, dy0, adx1), cyy0);
-            p[3] = __builtin_fmaf(dx1, __builtin_fmaf(co.y, dy1, adx1), cyy1);
-            bool cand[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) cand[k] = !done[k] && p[k] > ge.w;
-            if (!wave_any(cand[0] || cand[1] || cand[2] || cand[3])) continue;
             const float4 rgb = s_rgb[j];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (!wave_any(cand[k])) continue;
-                const float G = __builtin_amdgcn_exp2f(p[k]);
+                if (!((live[k] >> j) & 1ull)) continue;     // scalar test
+                const float dx = ge.x - ((k >> 1) ? fx1 : fx0), dy = ge.y - ((k & 1) ? fy1 : fy0);
+                const float adx = co.x * dx, cdy = co.z * dy;
+                const float p = __builtin_fmaf(dx, __builtin_fmaf(co.y, dy, adx), cdy * dy);
+                const float G = __builtin_amdgcn_exp2f(p);
                 const float alpha = fminf(ALPHA_MAX, ge.z * G);
-                const bool valid = cand[k] && !(p[k] > 0.0f) && !(alpha < ALPHA_MIN);
+                // p <= tau implies alpha < 1/255, so the alpha test alone decides; NaN powers fail p <= 0
+                const bool valid = p <= 0.0f && !(alpha < ALPHA_MIN);
                 float w = valid ? alpha * T[k] : 0.0f;
                 float tT = T[k] - w;
-                const bool brk = tT < T_MIN;
+                const bool brk = tT < thr[k];
                 if (wave_any(brk)) {   // rare: at most once per pixel
                     w = brk ? 0.0f : w;
-                    tT = brk ? T[k] : tT;
+                    Tfin[k] = brk ? T[k] : Tfin[k];
+                    tT = brk ? 0.0f : tT;
+                    thr[k] = brk ? 0.0f : thr[k];
                     last[k] = brk ? __float_as_int(co.w) + 1 : last[k];
-                    done[k] = done[k] || brk;
-                    broke[k] = broke[k] || brk;
                 }
                 C[k][0] = __builtin_fmaf(rgb.x, w, C[k][0]);
                 C[k][1] = __builtin_fmaf(rgb.y, w, C[k][1]);
@@ -551,11 +572,13 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
         const int px = X0 + qx + 8 * (k >> 1), py = Y0 + qy + 8 * (k & 1);
         if (px < a.W && py < a.H) {
             const size_t pidx = (size_t)px * a.H + py;
-            image[3 * pidx] = __builtin_fmaf(a.bg[0], T[k], C[k][0]);
-            image[3 * pidx + 1] = __builtin_fmaf(a.bg[1], T[k], C[k][1]);
-            image[3 * pidx + 2] = __builtin_fmaf(a.bg[2], T[k], C[k][2]);
-            n_contrib[pidx] = last[k] | (broke[k] ? (int32_t)0x80000000 : 0);
-            t_final[pidx] = T[k];
+            const bool broke = thr[k] == 0.0f;
+            const float Tk = broke ? Tfin[k] : T[k];
+            image[3 * pidx] = __builtin_fmaf(a.bg[0], Tk, C[k][0]);
+            image[3 * pidx + 1] = __builtin_fmaf(a.bg[1], Tk, C[k][1]);
+            image[3 * pidx + 2] = __builtin_fmaf(a.bg[2], Tk, C[k][2]);
+            n_contrib[pidx] = last[k] | (broke ? (int32_t)0x80000000 : 0);
+            t_final[pidx] = Tk;
         }
     }
     GS_STAMP_END(0, len);
@@ -579,6 +602,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     // its record is dead, so lane 63 parks the 9 reduced gradients in place: geo.xyzw, con.xyzw,
     // rgb.x; rgb.w keeps the gaussian id for the flush.
     __shared__ float4 s_rec_[QUAD_WAVES][3][64];
+    __shared__ unsigned s_qm_[QUAD_WAVES][64];
 
     const int wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * QUAD_WAVES + wv;
@@ -586,6 +610,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     GS_STAMP_BEGIN();
     float4 *s_geo = s_rec_[wv][0], *s_con = s_rec_[wv][1], *s_rgb = s_rec_[wv][2];
     const float *s_flat = reinterpret_cast<const float *>(s_rec_[wv]);
+    unsigned *s_qm = s_qm_[wv];
     const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
     const int lane = threadIdx.x & 63;
     const int qy = lane & 7, qx = lane >> 3;
@@ -593,7 +618,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     const float off = a.pixel_offset;
     const float fx0 = (float)(X0 + qx) - off, fx1 = fx0 + 8.0f;
     const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
-    const float xlo = (float)X0 - off, xhi = xlo + 15.0f, ylo = (float)Y0 - off, yhi = ylo + 15.0f;
+    const float xlo = (float)X0 - off, ylo = (float)Y0 - off;
     const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
 
     // lane 15 of row r finishes gradient words r and 4+r; the factors undo the log2 pre-scaling
@@ -629,24 +654,29 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
         my_max = max(my_max, end_k[k]);
     }
     const int max_end = wave_max_i32(my_max);
+    int qend[4];                             // wave-uniform: entries at or past it touch no pixel of quadrant k
+#pragma unroll
+    for (int k = 0; k < 4; k++) qend[k] = wave_max_i32(end_k[k]);
 
     const int nbatch = (max_end + 63) / 64;
     for (int b = nbatch - 1; b >= 0; b--) {
         const int base = b * 64;
         wave_lds_fence();                    // the previous batch's flush reads are complete
         const int i = base + lane;
-        bool keep = false;
+        unsigned qm = 0;
         float4 geo, con;
         int g = 0;
         if (i < max_end) {
             g = a.vals[rg.x + i];
             geo = a.rec[(size_t)g * 4];
             con = a.rec[(size_t)g * 4 + 1];
-            keep = tile_may_contribute(geo, con, xlo, xhi, ylo, yhi);
+            qm = quad_mask(geo, con, xlo, ylo);
+#pragma unroll
+            for (int k = 0; k < 4; k++) qm &= (i < qend[k]) ? ~0u : ~(1u << k);
         }
-        const unsigned long long m = __ballot(keep);
+        const unsigned long long m = __ballot(qm != 0u);
         const int n = __popcll(m);
-        if (keep) {
+        if (qm != 0u) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
             float4 rgb = a.rec[(size_t)g * 4 + 2];
             con.w = __int_as_float(i);
@@ -654,43 +684,37 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
             s_geo[pos] = geo;
             s_con[pos] = con;
             s_rgb[pos] = rgb;
+            s_qm[pos] = qm;
         }
         wave_lds_fence();
+        // live[k]: bitmap over the compacted entries that may touch quadrant k (scalar registers)
+        const unsigned myq = lane < n ? s_qm[lane] : 0u;
+        unsigned long long live[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) live[k] = __ballot((myq >> k) & 1u);
 
         unsigned long long touched = 0ull;   // wave-uniform: entries that received a gradient
-        for (int j = n - 1; j >= 0; j--) {
+        for (unsigned long long rem = live[0] | live[1] | live[2] | live[3]; rem != 0ull;) {
+            const int j = 63 - __builtin_clzll(rem);
+            rem &= ~(1ull << j);
             const float4 ge = s_geo[j];
             const float4 co = s_con[j];
             const int idx = __float_as_int(co.w);
-            const float dx0 = ge.x - fx0, dx1 = ge.x - fx1, dy0 = ge.y - fy0, dy1 = ge.y - fy1;
-            const float adx0 = co.x * dx0, adx1 = co.x * dx1;
-            const float cdy0 = co.z * dy0, cdy1 = co.z * dy1;
-            const float cyy0 = cdy0 * dy0, cyy1 = cdy1 * dy1;
-            float tt[4], p[4];
-            tt[0] = __builtin_fmaf(co.y, dy0, adx0);
-            tt[1] = __builtin_fmaf(co.y, dy1, adx0);
-            tt[2] = __builtin_fmaf(co.y, dy0, adx1);
-            tt[3] = __builtin_fmaf(co.y, dy1, adx1);
-            p[0] = __builtin_fmaf(dx0, tt[0], cyy0);
-            p[1] = __builtin_fmaf(dx0, tt[1], cyy1);
-            p[2] = __builtin_fmaf(dx1, tt[2], cyy0);
-            p[3] = __builtin_fmaf(dx1, tt[3], cyy1);
-            bool cand[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) cand[k] = idx < end_k[k] && p[k] > ge.w;
-            if (!wave_any(cand[0] || cand[1] || cand[2] || cand[3])) continue;
             const float4 rgb = s_rgb[j];
             float g_cx = 0.f, g_cy = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
             bool any_valid = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (!wave_any(cand[k])) continue;
-                const float dx = (k >> 1) ? dx1 : dx0, dy = (k & 1) ? dy1 : dy0;
-                const float adx = (k >> 1) ? adx1 : adx0, cdy = (k & 1) ? cdy1 : cdy0;
-                const float G = __builtin_amdgcn_exp2f(p[k]);
+                if (!((live[k] >> j) & 1ull)) continue;     // scalar test
+                const float dx = ge.x - ((k >> 1) ? fx1 : fx0), dy = ge.y - ((k & 1) ? fy1 : fy0);
+                const float adx = co.x * dx, cdy = co.z * dy;
+                const float tt = __builtin_fmaf(co.y, dy, adx);
+                const float p = __builtin_fmaf(dx, tt, cdy * dy);
+                const float G = __builtin_amdgcn_exp2f(p);
                 const float araw = ge.z * G;
                 const float alpha = fminf(ALPHA_MAX, araw);
-                const bool valid = cand[k] && !(p[k] > 0.0f) && !(alpha < ALPHA_MIN);
+                // the same decision as K6: p <= tau implies alpha < 1/255; NaN powers fail p <= 0
+                const bool valid = idx < end_k[k] && p <= 0.0f && !(alpha < ALPHA_MIN);
                 if (!wave_any(valid)) continue;
                 any_valid = true;
                 const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -707,7 +731,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                 const float dm = (valid && !(araw > ALPHA_MAX)) ? dLda : 0.0f;
                 g_o = __builtin_fmaf(G, dm, g_o);
                 const float q = araw * dm;                 // dL/dG * G
-                g_cx = __builtin_fmaf(q, tt[k] + adx, g_cx);                        // 2a'dx + b'dy
+                g_cx = __builtin_fmaf(q, tt + adx, g_cx);                           // 2a'dx + b'dy
                 g_cy = __builtin_fmaf(q, __builtin_fmaf(co.y, dx, cdy) + cdy, g_cy); // 2c'dy + b'dx
                 g_A = __builtin_fmaf(q, dx * dx, g_A);
                 g_B = __builtin_fmaf(q, dx * dy, g_B);
