@@ -701,15 +701,14 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
             const float4 co = s_con[j];
             const int idx = __float_as_int(co.w);
             const float4 rgb = s_rgb[j];
-            float g_cx = 0.f, g_cy = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+            float s_x = 0.f, s_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
             bool any_valid = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (!((live[k] >> j) & 1ull)) continue;     // scalar test
                 const float dx = ge.x - ((k >> 1) ? fx1 : fx0), dy = ge.y - ((k & 1) ? fy1 : fy0);
                 const float adx = co.x * dx, cdy = co.z * dy;
-                const float tt = __builtin_fmaf(co.y, dy, adx);
-                const float p = __builtin_fmaf(dx, tt, cdy * dy);
+                const float p = __builtin_fmaf(dx, __builtin_fmaf(co.y, dy, adx), cdy * dy);
                 const float G = __builtin_amdgcn_exp2f(p);
                 const float araw = ge.z * G;
                 const float alpha = fminf(ALPHA_MAX, araw);
@@ -717,10 +716,12 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                 const bool valid = idx < end_k[k] && p <= 0.0f && !(alpha < ALPHA_MIN);
                 if (!wave_any(valid)) continue;
                 any_valid = true;
-                const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                // lanes that skip this gaussian run with alpha = 0: inv = 1, T unchanged, w = 0
+                const float av = valid ? alpha : 0.0f;
+                const float inv = __builtin_amdgcn_rcpf(1.0f - av);
                 const float Tn = T[k] * inv;              // transmittance in front of this gaussian
-                T[k] = valid ? Tn : T[k];
-                const float w = valid ? alpha * Tn : 0.0f;
+                T[k] = Tn;
+                const float w = av * Tn;
                 const float cd = __builtin_fmaf(rgb.z, dLp[k][2], __builtin_fmaf(rgb.y, dLp[k][1], rgb.x * dLp[k][0]));
                 const float dLda = __builtin_fmaf(Tn, cd, -sacc[k] * inv);
                 sacc[k] = __builtin_fmaf(w, cd, sacc[k]);
@@ -731,16 +732,20 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                 const float dm = (valid && !(araw > ALPHA_MAX)) ? dLda : 0.0f;
                 g_o = __builtin_fmaf(G, dm, g_o);
                 const float q = araw * dm;                 // dL/dG * G
-                g_cx = __builtin_fmaf(q, tt + adx, g_cx);                           // 2a'dx + b'dy
-                g_cy = __builtin_fmaf(q, __builtin_fmaf(co.y, dx, cdy) + cdy, g_cy); // 2c'dy + b'dx
-                g_A = __builtin_fmaf(q, dx * dx, g_A);
-                g_B = __builtin_fmaf(q, dx * dy, g_B);
-                g_C = __builtin_fmaf(q, dy * dy, g_C);
+                const float qx = q * dx, qy = q * dy;
+                s_x += qx;
+                s_y += qy;
+                g_A = __builtin_fmaf(qx, dx, g_A);
+                g_B = __builtin_fmaf(qx, dy, g_B);
+                g_C = __builtin_fmaf(qy, dy, g_C);
             }
             if (!any_valid) continue;    // wave-uniform
             // 9 wave-wide sums in 6 lane swaps + 6 adds + 14 DPP adds instead of 54 DPP adds (a DPP add
             // issues in 4 cycles, twice a plain VALU op): permlane32/16 swaps fold two values per
             // instruction, leaving each 16-lane row with its own pair of values to finish.
+            // d power2/d cx = 2a' dx + b' dy and d power2/d cy = 2c' dy + b' dx, with (a', b', c') uniform
+            float g_cx = __builtin_fmaf(co.x + co.x, s_x, co.y * s_y);
+            float g_cy = __builtin_fmaf(co.z + co.z, s_y, co.y * s_x);
             swap32(g_cx, g_A); const float w0 = g_cx + g_A;
             swap32(g_cy, g_B); const float w1 = g_cy + g_B;
             swap32(g_C, g_r);  const float w2 = g_C + g_r;
