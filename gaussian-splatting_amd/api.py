@@ -283,11 +283,14 @@ class TileBinning:
 
 
 def match_gaus_to_tiles(ctx, queue, program, tiles_touched, radiis, depths,
-                        result_size=[979, 546], tile_size=16, *, want_keys=True):
+                        result_size=[979, 546], tile_size=16, *, want_keys=True, cull=None):
     """rasterization.py:6-25 (+ the per-tile filter/sort of :66-71).  `radiis` is accepted for
     signature compatibility; like the reference's kernel (quirk Q11) it does not affect the keys.
     want_keys=False skips materialising the 64-bit (tile<<32|depth) keys (the blend kernels only
-    need the gaussian ids and the tile ranges)."""
+    need the gaussian ids and the tile ranges).  cull=(centers, colors, opacities, conics,
+    pixel_offset) (float32 device tensors, the ones the blend calls will get) drops the pairs that
+    cannot change a pixel of their tile (gs_bin_*_culled): same images and gradients, about half
+    the list."""
     c = _ctx(ctx)
     c.sync_stream()
     dev = c.device
@@ -296,13 +299,26 @@ def match_gaus_to_tiles(ctx, queue, program, tiles_touched, radiis, depths,
     dep = _dev(depths, torch.int32, dev, (N,))
     W, H, ts = int(result_size[0]), int(result_size[1]), int(tile_size)
     D = ctypes.c_int64(0)
-    check(c.lib.gs_bin_count(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts, ctypes.byref(D)), "gs_bin_count")
+    extra = ()
+    if cull is not None:
+        cen, col, opa, con, off = cull
+        held = (_dev(cen, torch.float32, dev, (N, 2)), _dev(col, torch.float32, dev, (N, 3)),
+                _dev(opa, torch.float32, dev, (N,)), _dev(con, torch.float32, dev, (N, 3)))   # alive until the end
+        extra = tuple(_ptr(t) for t in held)
+        check(c.lib.gs_bin_count_culled(c.handle, N, _ptr(rect), _ptr(dep), *extra, W, H, ts, float(off),
+                                        ctypes.byref(D)), "gs_bin_count_culled")
+    else:
+        check(c.lib.gs_bin_count(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts, ctypes.byref(D)), "gs_bin_count")
     tiles = math.ceil(W / ts) * math.ceil(H / ts)
     keys = torch.empty((max(D.value, 1),), dtype=torch.int64, device=dev) if want_keys else None
     vals = torch.empty((max(D.value, 1),), dtype=torch.int32, device=dev)
     ranges = torch.empty((tiles, 2), dtype=torch.int32, device=dev)
-    check(c.lib.gs_bin_fill(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts, D.value, _ptr(keys), _ptr(vals),
-                            _ptr(ranges)), "gs_bin_fill")
+    if cull is not None:
+        check(c.lib.gs_bin_fill_culled(c.handle, N, _ptr(rect), _ptr(dep), *extra, W, H, ts, float(cull[4]), D.value,
+                                       _ptr(keys), _ptr(vals), _ptr(ranges)), "gs_bin_fill_culled")
+    else:
+        check(c.lib.gs_bin_fill(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts, D.value, _ptr(keys), _ptr(vals),
+                                _ptr(ranges)), "gs_bin_fill")
     return TileBinning(keys[:D.value] if want_keys else None, vals[:D.value], ranges, D.value, [W, H], ts)
 
 

@@ -248,6 +248,126 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
     }
 }
 
+// ------------------------------------------------------------------ culled variants of K2 / K3
+// The reference's rect (Q8/Q9) is the bounding square of 3 sigma of the LARGER axis: about half of its
+// tiles are never reached by the ellipse at alpha >= 1/255.  With the packed blend records at hand
+// the same exact box test the blend kernels use when staging decides per (gaussian, tile) pair, so
+// pairs that cannot change any pixel are never emitted, sorted or staged.  A list built this way is
+// the reference's list with those entries removed (same order); images and gradients are unchanged.
+struct CullBox {
+    float tile, off;   // tile size in pixels, pixel_offset
+};
+
+__device__ __forceinline__ bool pair_may_contribute(const float4 geo, const float4 con, int tx, int ty, CullBox cb) {
+    const float xlo = (float)tx * cb.tile - cb.off, ylo = (float)ty * cb.tile - cb.off;
+    return gs_box_may_contribute(geo, con, xlo, xlo + cb.tile - 1.0f, ylo, ylo + cb.tile - 1.0f);
+}
+
+// One wave per 64 consecutive gaussians; the wave walks the concatenation of their rects 64 pairs at a
+// time (binary search for the owner, as K3 does), so a gaussian covering thousands of tiles does not
+// serialise its wave.  CULL_EMIT = false: counts[g] <- pairs that pass.  CULL_EMIT = true (gaussians taken
+// in depth order through perm): the passing pairs are written from offsets[first position of the wave]
+// on, compacted with a ballot, i.e. in (depth order, tile order).
+template <bool CULL_EMIT>
+__global__ __launch_bounds__(256) void culled_pairs_kernel(int N, const int32_t *__restrict__ perm,
+                                                           const int4 *__restrict__ rect,
+                                                           const int32_t *__restrict__ depth, Grid grid,
+                                                           const float4 *__restrict__ rec, CullBox cb,
+                                                           uint32_t *__restrict__ counts,
+                                                           const uint32_t *__restrict__ offsets, uint32_t D,
+                                                           uint32_t *__restrict__ tile_keys,
+                                                           int32_t *__restrict__ vals) {
+    __shared__ uint32_t s_pref[4][64];   // inclusive prefix of rect sizes within the wave
+    __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
+    __shared__ float4 s_geo[4][64], s_con[4][64];
+    __shared__ uint32_t s_pass[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x * 4 + wave) * 64;
+    const int i = i0 + lane;
+    uint32_t cnt = 0;
+    int x0 = 0, y0 = 0, h = 1, g = 0;
+    float4 geo = make_float4(0.f, 0.f, 0.f, 0.f), con = geo;
+    if (i < N) {
+        g = CULL_EMIT ? perm[i] : i;
+        cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
+        if (cnt) {
+            geo = rec[(size_t)g * 4];
+            con = rec[(size_t)g * 4 + 1];
+        }
+    }
+    const uint32_t inc = wave_inclusive_scan(cnt);
+    s_pref[wave][lane] = inc;
+    s_info[wave][lane] = make_int4(x0, y0, h, g);
+    s_geo[wave][lane] = geo;
+    s_con[wave][lane] = con;
+    s_pass[wave][lane] = 0u;
+    const uint32_t wave_total = __shfl(inc, 63, 64);   // 0 when the whole wave is past N
+    uint32_t out = (CULL_EMIT && i0 < N) ? offsets[i0] : 0u;
+    __syncthreads();
+    for (uint32_t sbase = 0; sbase < wave_total; sbase += 64) {      // wave-uniform trip count
+        const uint32_t sidx = sbase + lane;
+        bool pass = false;
+        int lo = 0, tx = 0, ty = 0;
+        if (sidx < wave_total) {
+            int hi = 63;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pref[wave][mid] > sidx) hi = mid; else lo = mid + 1;
+            }
+            const int4 inf = s_info[wave][lo];
+            const uint32_t local = sidx - (lo ? s_pref[wave][lo - 1] : 0u);
+            tx = inf.x + (int)(local / (uint32_t)inf.z);
+            ty = inf.y + (int)(local % (uint32_t)inf.z);
+            pass = pair_may_contribute(s_geo[wave][lo], s_con[wave][lo], tx, ty, cb);
+        }
+        if (CULL_EMIT) {
+            const unsigned long long m = __ballot(pass);
+            if (pass) {
+                const uint32_t pos = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < D) {     // always true: the count pass ran the same test on the same data
+                    tile_keys[pos] = (uint32_t)(tx * grid.tiles_y + ty);
+                    vals[pos] = s_info[wave][lo].w;
+                }
+            }
+            out += (uint32_t)__popcll(m);
+        } else if (pass) {
+            atomicAdd(&s_pass[wave][lo], 1u);
+        }
+    }
+    if (!CULL_EMIT) {
+        __syncthreads();
+        if (i < N) counts[i] = s_pass[wave][lane];
+    }
+}
+
+// D and max depth from the culled counts (same partial layout as count_kernel)
+__global__ __launch_bounds__(SCAN_THREADS) void count_sum_kernel(int N, const uint32_t *__restrict__ counts,
+                                                                 const int32_t *__restrict__ depth,
+                                                                 ulonglong2 *__restrict__ partials) {
+    __shared__ uint32_t s_max[SCAN_THREADS / 64];
+    __shared__ unsigned long long s_sum[SCAN_THREADS / 64];
+    unsigned long long c = 0;
+    uint32_t md = 0;
+    for (int g = blockIdx.x * SCAN_THREADS + threadIdx.x; g < N; g += COUNT_BLOCKS * SCAN_THREADS) {
+        const uint32_t cg = counts[g];
+        c += cg;
+        if (cg) md = max(md, (uint32_t)depth[g]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        c += __shfl_xor(c, o, 64);
+        md = max(md, (uint32_t)__shfl_xor((int)md, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = md; s_sum[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        unsigned long long sum = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; w++) { m = max(m, s_max[w]); sum += s_sum[w]; }
+        partials[blockIdx.x] = make_ulonglong2(sum, m);
+    }
+}
+
 // ---------------------------------------------------------------------------- radix sort pass
 // digit = (key >> shift) & mask, at most 8 bits.  Block b owns keys [b*4096, (b+1)*4096).
 
@@ -455,11 +575,14 @@ int bits_of(uint32_t v) {
 
 }  // namespace
 
-extern "C" int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
-                            int32_t res_w, int32_t res_h, int32_t tile_size, int64_t *D_host) {
-    int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
-    if (rc) return rc;
+namespace {
+
+// rec == nullptr: the reference's rect semantics; otherwise pairs are culled with the box test
+int bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths, int32_t res_w,
+              int32_t res_h, int32_t tile_size, const float4 *rec, float pixel_offset, int64_t *D_host) {
+    int rc;
     GS_REQUIRE(D_host, "gs_bin_count: D_host is NULL");
+    ctx->bin_culled = rec != nullptr;
     ctx->bin_N = -1;
     ctx->bin_D = -1;
     ctx->bin_max_depth = 0;
@@ -476,9 +599,19 @@ extern "C" int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched
     ulonglong2 *partials = (ulonglong2 *)((char *)ctx->total.p + 16);
     {
         gs_prof_scope prof_(ctx, GS_K_COUNT);
-        hipLaunchKernelGGL(count_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
-                           reinterpret_cast<const int4 *>(tiles_touched), depths, grid, (uint32_t *)ctx->counts.p,
-                           partials);
+        if (rec) {
+            const CullBox cb{(float)tile_size, pixel_offset};
+            hipLaunchKernelGGL(culled_pairs_kernel<false>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+                               (const int32_t *)nullptr, reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
+                               rec, cb, (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr,
+                               (int32_t *)nullptr);
+            hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
+                               (const uint32_t *)ctx->counts.p, depths, partials);
+        } else {
+            hipLaunchKernelGGL(count_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
+                               reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
+                               (uint32_t *)ctx->counts.p, partials);
+        }
         hipLaunchKernelGGL(count_total_kernel, dim3(1), dim3(COUNT_BLOCKS), 0, ctx->stream,
                            (const ulonglong2 *)partials, (unsigned long long *)ctx->total.p);
     }
@@ -496,13 +629,12 @@ extern "C" int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched
     return GS_OK;
 }
 
-extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
-                           int32_t res_w, int32_t res_h, int32_t tile_size, int64_t D, uint64_t *keys,
-                           int32_t *vals, int32_t *ranges) {
-    int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
-    if (rc) return rc;
+int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths, int32_t res_w,
+             int32_t res_h, int32_t tile_size, const float4 *rec, float pixel_offset, int64_t D, uint64_t *keys,
+             int32_t *vals, int32_t *ranges) {
+    int rc;
     GS_REQUIRE(ranges, "gs_bin_fill: ranges is NULL");
-    if (ctx->bin_N != N || ctx->bin_D != D)
+    if (ctx->bin_N != N || ctx->bin_D != D || ctx->bin_culled != (rec != nullptr))
         return gs_set_error(GS_ERR_STATE, "gs_bin_fill: call gs_bin_count first with the same inputs "
                             "(have N=%d D=%lld, got N=%d D=%lld)", ctx->bin_N, (long long)ctx->bin_D, N,
                             (long long)D);
@@ -567,8 +699,15 @@ extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched,
     int cur = (tile_passes & 1) ? 0 : 1;
     {
         gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
-        hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm, rect,
-                           depths, grid, (const uint32_t *)ctx->offsets.p, tk[0], vb[cur]);
+        if (rec) {
+            const CullBox cb{(float)tile_size, pixel_offset};
+            hipLaunchKernelGGL(culled_pairs_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm,
+                               rect, depths, grid, rec, cb, (uint32_t *)nullptr, (const uint32_t *)ctx->offsets.p,
+                               (uint32_t)D, tk[0], vb[cur]);
+        } else {
+            hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm, rect,
+                               depths, grid, (const uint32_t *)ctx->offsets.p, tk[0], vb[cur]);
+        }
     }
     GS_HIP(hipGetLastError());
     int kcur = 0;
@@ -595,4 +734,54 @@ extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched,
     }
     GS_HIP(hipGetLastError());
     return GS_OK;
+}
+
+int cull_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,
+                 const float *conics, bool reuse, const float4 **rec) {
+    GS_REQUIRE(N == 0 || (centers && colors && opacities && conics), "gs_bin_*_culled: NULL gaussian array");
+    GS_REQUIRE(((uintptr_t)centers & 7) == 0, "gs_bin_*_culled: centers must be 8-byte aligned");
+    GS_HIP(hipSetDevice(ctx->device));
+    return gs_pack_records(ctx, N, centers, colors, opacities, conics, reuse, rec);
+}
+
+}  // namespace
+
+extern "C" int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                            int32_t res_w, int32_t res_h, int32_t tile_size, int64_t *D_host) {
+    int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
+    if (rc) return rc;
+    return bin_count(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, nullptr, 0.0f, D_host);
+}
+
+extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                           int32_t res_w, int32_t res_h, int32_t tile_size, int64_t D, uint64_t *keys,
+                           int32_t *vals, int32_t *ranges) {
+    int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
+    if (rc) return rc;
+    return bin_fill(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, nullptr, 0.0f, D, keys, vals, ranges);
+}
+
+extern "C" int gs_bin_count_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                                   const float *centers, const float *colors, const float *opacities,
+                                   const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
+                                   float pixel_offset, int64_t *D_host) {
+    int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
+    if (rc) return rc;
+    const float4 *rec = nullptr;
+    if ((rc = cull_records(ctx, N, centers, colors, opacities, conics, false, &rec))) return rc;
+    return bin_count(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, rec, pixel_offset, D_host);
+}
+
+extern "C" int gs_bin_fill_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                                  const float *centers, const float *colors, const float *opacities,
+                                  const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
+                                  float pixel_offset, int64_t D, uint64_t *keys, int32_t *vals, int32_t *ranges) {
+    int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
+    if (rc) return rc;
+    const float4 *rec = nullptr;
+    // the records packed by gs_bin_count_culled from the same arrays are still current
+    if ((rc = cull_records(ctx, N, centers, colors, opacities, conics, true, &rec))) return rc;
+    rc = bin_fill(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, rec, pixel_offset, D, keys, vals, ranges);
+    ctx->packed_fresh = rc == GS_OK;
+    return rc;
 }

@@ -380,32 +380,6 @@ __global__ __launch_bounds__(256) void pack_kernel(int N, const float2 *__restri
     rec[t] = v;
 }
 
-// max over the tile's pixel box of power2 >= tau ?  u = cx - x in [ulo,uhi], v likewise.
-// Q = alpha u^2 + beta u v + gamma v^2 is convex; outside the origin its box minimum lies on one
-// of the four edges.  NaNs (degenerate conics) fall through to "keep".
-__device__ __forceinline__ bool tile_may_contribute(const float4 geo, const float4 con, float xlo, float xhi,
-                                                    float ylo, float yhi) {
-    const float ulo = geo.x - xhi, uhi = geo.x - xlo, vlo = geo.y - yhi, vhi = geo.y - ylo;
-    const float al = -con.x, be = -con.y, ga = -con.z;
-    float qmin;
-    if (ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f) {
-        qmin = 0.0f;
-    } else {
-        const float inv2g = 0.5f / ga, inv2a = 0.5f / al;
-        float v = fminf(fmaxf(-be * ulo * inv2g, vlo), vhi);
-        float q0 = al * ulo * ulo + (be * ulo + ga * v) * v;
-        v = fminf(fmaxf(-be * uhi * inv2g, vlo), vhi);
-        float q1 = al * uhi * uhi + (be * uhi + ga * v) * v;
-        float u = fminf(fmaxf(-be * vlo * inv2a, ulo), uhi);
-        float q2 = ga * vlo * vlo + (be * vlo + al * u) * u;
-        u = fminf(fmaxf(-be * vhi * inv2a, ulo), uhi);
-        float q3 = ga * vhi * vhi + (be * vhi + al * u) * u;
-        qmin = fminf(fminf(q0, q1), fminf(q2, q3));
-    }
-    // relative slack on qmin covers the rounding of the edge evaluation itself
-    return !(-qmin * 0.999f + 1e-4f < geo.w);
-}
-
 // bit k set: the gaussian may reach alpha >= 1/255 somewhere in 8x8 quadrant k of the tile
 // (k>>1: x half, k&1: y half; the quadrant's pixel box spans 7 pixels each way).  Evaluated once per
 // staged entry by ONE lane, so that the 64 lanes never evaluate a quadrant the gaussian misses.
@@ -414,7 +388,7 @@ __device__ __forceinline__ unsigned quad_mask(const float4 geo, const float4 con
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float x0 = xlo + (float)(8 * (k >> 1)), y0 = ylo + (float)(8 * (k & 1));
-        m |= tile_may_contribute(geo, con, x0, x0 + 7.0f, y0, y0 + 7.0f) ? (1u << k) : 0u;
+        m |= gs_box_may_contribute(geo, con, x0, x0 + 7.0f, y0, y0 + 7.0f) ? (1u << k) : 0u;
     }
     return m;
 }
@@ -802,18 +776,11 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(int N, const float *__
 // reuse = the caller is gs_blend_backward*: it must be given the arrays of the forward call whose
 // n_contrib/t_final it consumes, so the records packed by that forward call are still valid.
 int fill_quad(QuadArgs &q, const BlendArgs &a, gs_ctx *ctx, int32_t N, bool reuse = false) {
-    int rc = gs_buf_reserve(ctx, &ctx->packed, (size_t)(N > 0 ? N : 1) * 64);
+    const float4 *rec = nullptr;
+    int rc = gs_pack_records(ctx, N, reinterpret_cast<const float *>(a.centers), a.colors, a.opacities, a.conics,
+                             reuse || ctx->packed_fresh, &rec);
     if (rc) return rc;
-    float4 *rec = (float4 *)ctx->packed.p;
-    const void *key[4] = {a.centers, a.colors, a.opacities, a.conics};
-    const bool cached = reuse && ctx->packed_N == N && memcmp(key, ctx->packed_key, sizeof key) == 0;
-    memcpy(ctx->packed_key, key, sizeof key);
-    ctx->packed_N = N;
-    if (N > 0 && !cached) {
-        gs_prof_scope prof_(ctx, GS_K_PACK);
-        hipLaunchKernelGGL(pack_kernel, dim3(gs_div_up(N, 64)), dim3(256), 0, ctx->stream, N, a.centers, a.colors,
-                           a.opacities, a.conics, rec);
-    }
+    ctx->packed_fresh = false;
     q.rec = rec; q.vals = a.vals; q.ranges = a.ranges;
     q.bg[0] = a.bg[0]; q.bg[1] = a.bg[1]; q.bg[2] = a.bg[2];
     q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
@@ -847,6 +814,24 @@ int fill_args(BlendArgs &a, gs_ctx *ctx, int32_t N, const float *centers, const 
 }
 
 }  // namespace
+
+int gs_pack_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,
+                    const float *conics, bool reuse, const float4 **rec_out) {
+    int rc = gs_buf_reserve(ctx, &ctx->packed, (size_t)(N > 0 ? N : 1) * 64);
+    if (rc) return rc;
+    float4 *rec = (float4 *)ctx->packed.p;
+    const void *key[4] = {centers, colors, opacities, conics};
+    const bool cached = reuse && ctx->packed_N == N && memcmp(key, ctx->packed_key, sizeof key) == 0;
+    memcpy(ctx->packed_key, key, sizeof key);
+    ctx->packed_N = N;
+    if (N > 0 && !cached) {
+        gs_prof_scope prof_(ctx, GS_K_PACK);
+        hipLaunchKernelGGL(pack_kernel, dim3(gs_div_up(N, 64)), dim3(256), 0, ctx->stream, N,
+                           reinterpret_cast<const float2 *>(centers), colors, opacities, conics, rec);
+    }
+    *rec_out = rec;
+    return GS_OK;
+}
 
 extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
                                 const float *opacities, const float *conics, const int32_t *vals,

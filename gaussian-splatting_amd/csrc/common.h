@@ -72,6 +72,8 @@ struct gs_ctx {
     // arrays the packed blend records were built from (gs_blend_forward -> gs_blend_backward reuse)
     const void *packed_key[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t packed_N = -1;
+    bool packed_fresh = false;   // gs_bin_fill_culled packed them: the next gs_blend_forward may reuse them
+    bool bin_culled = false;     // gs_bin_count_culled produced bin_N / bin_D
 };
 
 int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);
@@ -86,3 +88,39 @@ struct gs_prof_scope {
 };
 
 static inline int gs_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- per-gaussian blend records (blend.hip packs them; the culled binning reads them too) ----
+// one 64-byte record per gaussian, so that staging an entry touches ONE cache line:
+//   [0] geo = cx, cy, opacity, tau     tau = log2(1/255 / opacity) - margin
+//   [1] con = a', b', c', 0            log2-scaled: power2 = a' dx^2 + b' dx dy + c' dy^2
+//   [2] rgb = r, g, b, 0               [3] zero
+// Packs the four arrays into ctx->packed on ctx->stream unless `reuse` and the same arrays were
+// packed last; *rec gets the record array.
+int gs_pack_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,
+                    const float *conics, bool reuse, const float4 **rec);
+
+// max over the pixel box [xlo,xhi]x[ylo,yhi] of power2 >= tau ?  u = cx - x in [ulo,uhi], v likewise.
+// Q = alpha u^2 + beta u v + gamma v^2 is convex; outside the origin its box minimum lies on one
+// of the four edges.  NaNs (degenerate conics) fall through to "keep".
+__device__ __forceinline__ bool gs_box_may_contribute(const float4 geo, const float4 con, float xlo, float xhi,
+                                                      float ylo, float yhi) {
+    const float ulo = geo.x - xhi, uhi = geo.x - xlo, vlo = geo.y - yhi, vhi = geo.y - ylo;
+    const float al = -con.x, be = -con.y, ga = -con.z;
+    float qmin;
+    if (ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f) {
+        qmin = 0.0f;
+    } else {
+        const float inv2g = 0.5f / ga, inv2a = 0.5f / al;
+        float v = fminf(fmaxf(-be * ulo * inv2g, vlo), vhi);
+        float q0 = al * ulo * ulo + (be * ulo + ga * v) * v;
+        v = fminf(fmaxf(-be * uhi * inv2g, vlo), vhi);
+        float q1 = al * uhi * uhi + (be * uhi + ga * v) * v;
+        float u = fminf(fmaxf(-be * vlo * inv2a, ulo), uhi);
+        float q2 = ga * vlo * vlo + (be * vlo + al * u) * u;
+        u = fminf(fmaxf(-be * vhi * inv2a, ulo), uhi);
+        float q3 = ga * vhi * vhi + (be * vhi + al * u) * u;
+        qmin = fminf(fminf(q0, q1), fminf(q2, q3));
+    }
+    // relative slack on qmin covers the rounding of the edge evaluation itself
+    return !(-qmin * 0.999f + 1e-4f < geo.w);
+}

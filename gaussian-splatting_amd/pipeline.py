@@ -60,8 +60,9 @@ class SplatPipeline:
     """Holds the parameters on one device and runs views through the native kernels."""
 
     def __init__(self, gaussians, result_size, tile_size=16, background=(0., 0., 0.), pixel_offset=0.5,
-                 opacity_is_logit=True, ctx=None):
+                 opacity_is_logit=True, ctx=None, cull_tiles=True):
         self.ctx = api._ctx(ctx)
+        self.cull_tiles = bool(cull_tiles)   # gs_bin_*_culled: same images/gradients, about half the list
         dev = self.ctx.device
         self.N, self.means, self.log_scales, self.quats, self.sh = api._gaussian_tensors(gaussians, dev)
         self.opacity = api._dev(gaussians.opacity, torch.float32, dev, (self.N,))
@@ -112,6 +113,9 @@ class SplatPipeline:
                 setattr(arr[k], name, p[key].data_ptr())
         check(c.lib.gs_preprocess_batch(c.handle, self.N, api._ptr(self.means), api._ptr(self.log_scales),
                                         api._ptr(self.quats), api._ptr(self.sh), len(pres), arr), "gs_preprocess_batch")
+        opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity   # once for the batch
+        for p in pres:
+            p["opac"] = opac
         return pres
 
     def forward(self, view, want_keys=False, ctx=None, pre=None):
@@ -129,9 +133,12 @@ class SplatPipeline:
                                       api._ptr(pre["radii"]), null, null, null, null, null, null), "gs_preprocess")
         cam, centers, depths, colors, conics = pre["cam"], pre["centers"], pre["depths"], pre["colors"], pre["conics"]
         clamped, rect, radii = pre["clamped"], pre["rect"], pre["radii"]
+        opac = pre.get("opac")
+        if opac is None:
+            opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
+        cull = (centers, colors, opac, conics, self.pixel_offset) if self.cull_tiles else None
         binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size, self.tile_size,
-                                          want_keys=want_keys)
-        opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
+                                          want_keys=want_keys, cull=cull)
         image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
                                                       self.pixel_offset)
         state = dict(ctx=c, cam=cam, depths=depths, centers=centers, colors=colors, conics=conics, clamped=clamped,

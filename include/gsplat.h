@@ -101,6 +101,25 @@ int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int3
                 int32_t res_w, int32_t res_h, int32_t tile_size, int64_t D,
                 uint64_t *keys, int32_t *vals, int32_t *ranges);
 
+/* Culled form of the two calls above (no counterpart in the reference): a (gaussian, tile) pair of
+ * the reference's rect (forward_pass.py:114-120: the bounding square of 3 sigma of the LARGER axis)
+ * is emitted only if the gaussian can reach alpha >= 1/255 (rasterize.c:114) somewhere in the tile's
+ * pixel box -- the test the blend kernels apply when they stage a list.  The result is the list of
+ * gs_bin_fill with those pairs removed, in the same order: gs_blend_forward / gs_blend_backward
+ * give the same image and gradients from either list (n_contrib counts positions of the list it was
+ * produced from, so forward and backward must use the same one), while D -- what is sorted, written
+ * and staged -- is about halved.  centers / colors / opacities / conics are the arrays the blend
+ * calls will be given (they are packed into the ctx's blend records here; a gs_blend_forward that
+ * directly follows gs_bin_fill_culled on this ctx with the same arrays reuses them). */
+int gs_bin_count_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                        const float *centers, const float *colors, const float *opacities,
+                        const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
+                        float pixel_offset, int64_t *D_host);
+int gs_bin_fill_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                       const float *centers, const float *colors, const float *opacities,
+                       const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
+                       float pixel_offset, int64_t D, uint64_t *keys, int32_t *vals, int32_t *ranges);
+
 /* Replaces gpu_rasterize forward (rasterization.py:27-107 + kernel rasterize,
  * setup_gpu.py:46-100), c_rasterize/rasterize_tile (rasterization.py:109-153, rasterize.c:27-132)
  * and rasterize (rasterization.py:155-215): one launch for the whole frame.

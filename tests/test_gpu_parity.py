@@ -455,13 +455,18 @@ def test_config4_stress_4k_heavy_overlap(gpu_ctx):
     import gsplat_amd as gs
     W, H = 3840, 2160
     cam, R, t, g, rs = synth_scene(1_000_000, W, H, seed=9, log_scale=(2.0, 4.0))
-    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx, cull_tiles=False)   # the reference's lists
     image, st = pipe.forward(gs.View(cam, R, t), want_keys=True)
     b = st["binning"]
     assert b.tiles_x == 240 and b.tiles_y == 135 and b.D > 20_000_000
     _device_binning_properties(b, st["depths"], b.tiles_y)
     image2, st2 = pipe.forward(gs.View(cam, R, t))
     assert torch.equal(image, image2) and torch.equal(st2["binning"].vals, b.vals)
+    # the culled lists (the pipeline's default): far fewer pairs, the same image bit for bit
+    pipe_c = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    image_c, st_c = pipe_c.forward(gs.View(cam, R, t), want_keys=True)
+    assert st_c["binning"].D < 0.7 * b.D and torch.equal(image_c, image)
+    _device_binning_properties(st_c["binning"], st_c["depths"], b.tiles_y)
     # tile columns 100..103 (64 pixel columns) against the C oracle
     tx0, tx1 = 100, 104
     ranges = b.ranges.cpu().numpy().reshape(240, 135, 2)[tx0:tx1].reshape(-1, 2).copy()
@@ -603,3 +608,60 @@ def test_preprocess_edge_cases_vs_oracle(gpu_ctx):
     assert out[6][0] == 0 and out[6][2] == 0 and out[6][3] == 0 and out[6][4] == 0      # culled: radius 0
     assert out[1][1] == 2000 and out[1][0] == 0        # z = 2.0000002 passes the near cull, z = 2 does not
     assert out[1][5] != 0 and out[1][6] != 0          # wrapped, not zero
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile,W,H,ls", [(16, 640, 360, (1.0, 3.0)), (32, 500, 300, (1.5, 3.5)), (16, 333, 211, (-1.0, 4.0))])
+def test_culled_binning_is_the_exact_list_minus_dead_pairs(gpu_ctx, tile, W, H, ls):
+    """gs_bin_*_culled (no counterpart in the reference): per tile the culled list is a subsequence
+    of the reference-exact list, every removed pair is one the fp64 oracle says cannot reach
+    alpha >= 1/255 in the tile (so no pixel changes), the forward image / t_final are bit-identical
+    and the gradients agree to float-atomics noise."""
+    import torch
+    import gsplat_amd as gs
+    cam, R, t, g, rs = synth_scene(30_000, W, H, seed=11, log_scale=ls)
+    out = gs.forward_pass(gpu_ctx, None, None, cam, R, t, g, result_size=rs, tile_size=tile, training=False)
+    dev = gpu_ctx.device
+    centers, depths, colors, conics, tiles_touched, radii = out
+    cen, col, con = (torch.tensor(np.asarray(a, dtype=np.float32), device=dev) for a in (centers, colors, conics))
+    opa = torch.tensor(np.asarray(g.opacity, dtype=np.float32).reshape(-1), device=dev)
+    exact = gs.match_gaus_to_tiles(gpu_ctx, None, None, tiles_touched, radii, depths, result_size=rs, tile_size=tile)
+    culled = gs.match_gaus_to_tiles(gpu_ctx, None, None, tiles_touched, radii, depths, result_size=rs,
+                                    tile_size=tile, cull=(cen, col, opa, con, 0.5))
+    assert 0 < culled.D < exact.D
+    _device_binning_properties(culled, torch.tensor(depths, device=dev), culled.tiles_y)
+    ev, er = exact.vals.cpu().numpy(), exact.ranges.cpu().numpy()
+    cv, cr = culled.vals.cpu().numpy(), culled.ranges.cpu().numpy()
+    cen64, con64, opa64 = (np.asarray(a, dtype=np.float32).astype(np.float64) for a in (centers, conics, g.opacity.reshape(-1)))
+    removed = 0
+    for tidx in range(er.shape[0]):
+        full, part = ev[er[tidx, 0]:er[tidx, 1]], cv[cr[tidx, 0]:cr[tidx, 1]]
+        keep = np.isin(full, part)                       # a gaussian appears at most once per tile
+        assert np.array_equal(full[keep], part), tidx    # same order, nothing added
+        gone = full[~keep]
+        if gone.size == 0:
+            continue
+        removed += gone.size
+        # brute force over the tile's pixel centres in fp64: alpha stays below 1/255 everywhere
+        tx, ty = divmod(tidx, exact.tiles_y)
+        xs = np.arange(tx * tile, (tx + 1) * tile) - 0.5
+        ys = np.arange(ty * tile, (ty + 1) * tile) - 0.5
+        dx = cen64[gone, 0][:, None, None] - xs[None, :, None]
+        dy = cen64[gone, 1][:, None, None] - ys[None, None, :]
+        A, B, C = (con64[gone, k][:, None, None] for k in range(3))
+        power = -0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy
+        alpha = np.minimum(0.99, opa64[gone][:, None, None] * np.exp(np.minimum(power, 0.0)))
+        alpha = np.where(power > 0, 0.0, alpha)
+        assert alpha.max() < 1.0 / 255.0, (tidx, alpha.max())
+    assert removed == exact.D - culled.D
+    bg = gs.api._bg3(np.array([0.1, 0.2, 0.3]))
+    img_e, nc_e, tf_e = gs.api.blend_forward(gpu_ctx, cen, col, opa, con, exact, bg, 0.5)
+    img_c, nc_c, tf_c = gs.api.blend_forward(gpu_ctx, cen, col, opa, con, culled, bg, 0.5)
+    assert torch.equal(img_e, img_c) and torch.equal(tf_e, tf_c)
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    dL = torch.randn(W, H, 3, generator=gen).to(dev)
+    ge = gs.api.blend_backward(gpu_ctx, cen, col, opa, con, exact, bg, 0.5, nc_e, tf_e, dL)
+    gc = gs.api.blend_backward(gpu_ctx, cen, col, opa, con, culled, bg, 0.5, nc_c, tf_c, dL)
+    for a, b_ in zip(ge, gc):
+        scale = a.abs().max().item()
+        assert (a - b_).abs().max().item() <= 1e-5 * scale

@@ -2,6 +2,10 @@
 per-kernel counters must not overlap).  GS_VIEWS views, then one batched parameter backward."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib
+if os.environ.get("GS_VARIANT"):      # a tools/libgsplat_<name>.so built by variant_bench.py
+    _lib = importlib.import_module("gaussian-splatting_amd._lib")
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgsplat_%s.so" % os.environ["GS_VARIANT"])
 import torch
 import gsplat_amd as gs
 from bench import make_scene, make_views
