@@ -9,7 +9,9 @@ import collections, csv, glob, json, re, sys
 SHORT = [("blend_bwd_quad", "blend_backward"), ("blend_fwd_quad", "blend_forward"), ("param_bwd", "param_backward"),
          ("preprocess_batch_kernel", "preprocess"), ("preprocess_kernel", "preprocess"), ("image_loss_kernel", "image_loss"), ("radix_scatter", "radix_scatter"), ("radix_hist", "radix_hist"),
          ("radix_scan", "radix_scan"), ("duplicate_kernel", "bin_duplicate"), ("pack_kernel", "blend_pack"),
-         ("count_kernel", "bin_count"), ("ranges_kernel", "bin_ranges"), ("sorted_offsets", "bin_offsets"),
+         ("culled_pairs_kernel<false>", "bin_count_culled"), ("culled_pairs_kernel<true>", "bin_duplicate_culled"),
+         ("culled_pairs_kernel<(bool)0>", "bin_count_culled"), ("culled_pairs_kernel<(bool)1>", "bin_duplicate_culled"),
+         ("count_sum_kernel", "bin_count_sum"), ("count_kernel", "bin_count"), ("ranges_kernel", "bin_ranges"), ("sorted_offsets", "bin_offsets"),
          ("sorted_block_sums", "bin_block_sums")]
 
 
