@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--views", type=int, default=0, help="fixed GLOBAL batch instead (strong scaling; needs --views-per-rank 0)")
     ap.add_argument("--log-scale", type=float, nargs=2, default=(1.0, 3.0))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-timing", choices=["dominant", "all", "none"], default="dominant",
+                    help="which kernels get HIP events inside the timed region")
     ap.add_argument("--k1-first", type=int, default=0, help="views in the first preprocess launch (0: one per lane)")
     ap.add_argument("--k8-tail", type=int, default=None,
                     help="views left to the final parameter-backward launch (the rest start early on the main stream; 0: one launch)")
@@ -153,8 +155,15 @@ def main():
     barrier()
     mark("barrier passed")
     ctxs = [ctx] + ([c for c, _ in pipe.lanes(min(args.concurrent_views, 4) - (1 if args.concurrent_views > 3 else 0))] if args.concurrent_views > 1 else [])
+    # HIP events around every launch cost 0.3 ms of host time per step; by default only the roofline
+    # kernel is timed inside the timed region (--kernel-timing all: every kernel, for the `kernels` table)
+    names = [ctx.lib.gs_profile_kernel_name(i).decode() for i in range(ctx.lib.gs_profile_kernel_count())]
+    # the candidates for "dominant": blend backward (forward when --forward-only) and the tile sort
+    few = sum(1 << names.index(k) for k in (("blend_forward",) if args.forward_only else ("blend_backward",)) + ("bin_sort",)) if names else 0
     for c in ctxs:
-        c.profile(True)
+        mask = 0x7FFFFFFF if args.kernel_timing == "all" else few
+        c.set_option("profile_mask", mask)
+        c.profile(args.kernel_timing != "none")
         c.read_profile()
     barrier()
     t0 = time.perf_counter()
@@ -168,6 +177,7 @@ def main():
             a = prof.get(k, (0.0, 0))
             prof[k] = (a[0] + ms, a[1] + cnt)
         c.profile(False)
+        c.set_option("profile_mask", 0x7FFFFFFF)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

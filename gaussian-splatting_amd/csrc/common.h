@@ -63,6 +63,7 @@ struct gs_ctx {
     uint64_t *total_host = nullptr;   // pinned, 2 words
     // state carried from gs_bin_count to gs_bin_fill
     bool prof_on = false;
+    uint32_t prof_mask = 0xFFFFFFFFu;         // kernel ids that are timed when prof_on (option profile_mask)
     std::vector<gs_prof_span> prof_spans;     // recorded, not yet read
     std::vector<hipEvent_t> prof_free;        // recycled events
     int ppt = 4;         // pixels per thread of the blend kernels (1, 2 or 4)

@@ -61,6 +61,10 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
         ctx->ppt = value;
         return GS_OK;
     }
+    if (strcmp(name, "profile_mask") == 0) {   // bit i: time kernel id i (gs_profile_kernel_name) when profiling is on
+        ctx->prof_mask = (uint32_t)value;
+        return GS_OK;
+    }
     return gs_set_error(GS_ERR_ARG, "gs_ctx_set_option: unknown option '%s'", name);
 }
 
@@ -80,7 +84,7 @@ static hipEvent_t prof_event(gs_ctx *c) {
 }
 
 gs_prof_scope::gs_prof_scope(gs_ctx *c, int kernel) : ctx(c) {
-    if (!c || !c->prof_on) return;
+    if (!c || !c->prof_on || !((c->prof_mask >> kernel) & 1u)) return;
     span.kernel = kernel;
     span.start = prof_event(c);
     span.stop = prof_event(c);
