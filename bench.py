@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timing", choices=["dominant", "all", "none"], default="dominant",
                     help="which kernels get HIP events inside the timed region")
+    ap.add_argument("--k8-early-lanes", type=int, default=None,
+                    help="lanes whose views get an early parameter-backward launch (default: half of them)")
     ap.add_argument("--k1-first", type=int, default=0, help="views in the first preprocess launch (0: one per lane)")
     ap.add_argument("--k8-tail", type=int, default=None,
                     help="views left to the final parameter-backward launch (the rest start early on the main stream; 0: one launch)")
@@ -134,7 +136,7 @@ def main():
             image, _ = pipe.forward(views[0])
             return image
         return gs.train_step(pipe, views, targets, grads, concurrent_views=args.concurrent_views,
-                             k8_tail=args.k8_tail, k1_first=args.k1_first)
+                             k8_tail=args.k8_tail, k1_first=args.k1_first, k8_early_lanes=args.k8_early_lanes)
 
     trace = os.environ.get("GS_BENCH_TRACE") == "1"
 
@@ -154,7 +156,7 @@ def main():
         mark("warmup step done")
     barrier()
     mark("barrier passed")
-    ctxs = [ctx] + ([c for c, _ in pipe.lanes(min(args.concurrent_views, 4) - (1 if args.concurrent_views > 3 else 0))] if args.concurrent_views > 1 else [])
+    ctxs = pipe.contexts()      # the warm-up steps created every lane's contexts
     # HIP events around every launch cost 0.3 ms of host time per step; by default only the roofline
     # kernel is timed inside the timed region (--kernel-timing all: every kernel, for the `kernels` table)
     names = [ctx.lib.gs_profile_kernel_name(i).decode() for i in range(ctx.lib.gs_profile_kernel_count())]

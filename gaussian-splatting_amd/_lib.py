@@ -52,6 +52,8 @@ SIGNATURES = {
     "gs_bin_fill": (ctypes.c_int, [_P, _I32, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P]),
     "gs_bin_count_culled": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float,
                                            ctypes.POINTER(_I64)]),
+    "gs_bin_count_culled_begin": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float]),
+    "gs_bin_count_end": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
     "gs_bin_fill_culled": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float, _I64,
                                           _P, _P, _P]),
     "gs_blend_forward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),

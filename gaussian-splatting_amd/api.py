@@ -322,6 +322,42 @@ def match_gaus_to_tiles(ctx, queue, program, tiles_touched, radiis, depths,
     return TileBinning(keys[:D.value] if want_keys else None, vals[:D.value], ranges, D.value, [W, H], ts)
 
 
+def bin_culled_begin(ctx, tiles_touched, depths, result_size, tile_size, cull):
+    """First half of match_gaus_to_tiles(..., cull=...) (gs_bin_count_culled_begin): launches the count on
+    the ctx's stream and returns a token for bin_culled_finish; the host does not wait."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    dev = c.device
+    N = len(depths)
+    rect = _dev(tiles_touched, torch.int32, dev, (N, 4))
+    dep = _dev(depths, torch.int32, dev, (N,))
+    W, H, ts = int(result_size[0]), int(result_size[1]), int(tile_size)
+    cen, col, opa, con, off = cull
+    held = (_dev(cen, torch.float32, dev, (N, 2)), _dev(col, torch.float32, dev, (N, 3)),
+            _dev(opa, torch.float32, dev, (N,)), _dev(con, torch.float32, dev, (N, 3)))
+    extra = tuple(_ptr(t) for t in held)
+    check(c.lib.gs_bin_count_culled_begin(c.handle, N, _ptr(rect), _ptr(dep), *extra, W, H, ts, float(off)),
+          "gs_bin_count_culled_begin")
+    return dict(c=c, N=N, rect=rect, dep=dep, held=held, extra=extra, W=W, H=H, ts=ts, off=float(off))
+
+
+def bin_culled_finish(tok, want_keys=False):
+    """Second half: waits for the count only (gs_bin_count_end), then sorts (gs_bin_fill_culled)."""
+    c = tok["c"]
+    c.sync_stream()
+    dev = c.device
+    D = ctypes.c_int64(0)
+    check(c.lib.gs_bin_count_end(c.handle, ctypes.byref(D)), "gs_bin_count_end")
+    W, H, ts, N = tok["W"], tok["H"], tok["ts"], tok["N"]
+    tiles = math.ceil(W / ts) * math.ceil(H / ts)
+    keys = torch.empty((max(D.value, 1),), dtype=torch.int64, device=dev) if want_keys else None
+    vals = torch.empty((max(D.value, 1),), dtype=torch.int32, device=dev)
+    ranges = torch.empty((tiles, 2), dtype=torch.int32, device=dev)
+    check(c.lib.gs_bin_fill_culled(c.handle, N, _ptr(tok["rect"]), _ptr(tok["dep"]), *tok["extra"], W, H, ts,
+                                   tok["off"], D.value, _ptr(keys), _ptr(vals), _ptr(ranges)), "gs_bin_fill_culled")
+    return TileBinning(keys[:D.value] if want_keys else None, vals[:D.value], ranges, D.value, [W, H], ts)
+
+
 def _binning_from_lists(mapped_keys, result_size, tile_size, device):
     """Accept the dict format the reference's c_rasterize/rasterize expect
     (mapped_keys[i][j] = {depth: gaussian}, rasterization.py:132,167)."""

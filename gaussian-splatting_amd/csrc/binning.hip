@@ -577,25 +577,25 @@ int bits_of(uint32_t v) {
 
 namespace {
 
-// rec == nullptr: the reference's rect semantics; otherwise pairs are culled with the box test
-int bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths, int32_t res_w,
-              int32_t res_h, int32_t tile_size, const float4 *rec, float pixel_offset, int64_t *D_host) {
+// rec == nullptr: the reference's rect semantics; otherwise pairs are culled with the box test.
+// Launches the count and the copy of (D, max depth) to pinned memory, and records count_event.
+int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths, int32_t res_w,
+                    int32_t res_h, int32_t tile_size, const float4 *rec, float pixel_offset) {
     int rc;
-    GS_REQUIRE(D_host, "gs_bin_count: D_host is NULL");
     ctx->bin_culled = rec != nullptr;
     ctx->bin_N = -1;
     ctx->bin_D = -1;
     ctx->bin_max_depth = 0;
-    *D_host = 0;
+    ctx->count_pending_N = -1;
     if (N == 0) {
-        ctx->bin_N = 0;
-        ctx->bin_D = 0;
+        ctx->count_pending_N = 0;
         return GS_OK;
     }
     GS_HIP(hipSetDevice(ctx->device));
     const Grid grid{gs_div_up(res_w, tile_size), gs_div_up(res_h, tile_size)};
     if ((rc = gs_buf_reserve(ctx, &ctx->counts, (size_t)N * 4))) return rc;
     if ((rc = gs_buf_reserve(ctx, &ctx->total, 16 + COUNT_BLOCKS * sizeof(ulonglong2)))) return rc;
+    if (!ctx->count_event) GS_HIP(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
     ulonglong2 *partials = (ulonglong2 *)((char *)ctx->total.p + 16);
     {
         gs_prof_scope prof_(ctx, GS_K_COUNT);
@@ -617,7 +617,25 @@ int bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_
     }
     GS_HIP(hipGetLastError());
     GS_HIP(hipMemcpyAsync(ctx->total_host, ctx->total.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    GS_HIP(hipStreamSynchronize(ctx->stream));
+    GS_HIP(hipEventRecord(ctx->count_event, ctx->stream));
+    ctx->count_pending_N = N;
+    return GS_OK;
+}
+
+// waits for the count launched by bin_count_begin (only for it: later work on the stream may still run)
+int bin_count_end(gs_ctx *ctx, int64_t *D_host) {
+    GS_REQUIRE(D_host, "gs_bin_count: D_host is NULL");
+    *D_host = 0;
+    if (ctx->count_pending_N < 0)
+        return gs_set_error(GS_ERR_STATE, "gs_bin_count_end: no gs_bin_count*_begin is pending on this ctx");
+    const int32_t N = ctx->count_pending_N;
+    ctx->count_pending_N = -1;
+    if (N == 0) {
+        ctx->bin_N = 0;
+        ctx->bin_D = 0;
+        return GS_OK;
+    }
+    GS_HIP(hipEventSynchronize(ctx->count_event));
     const uint64_t D = ctx->total_host[0];
     if (D >= (1ull << 31))
         return gs_set_error(GS_ERR_ARG, "gs_bin_count: %llu duplicates exceed the 2^31-1 limit",
@@ -750,7 +768,9 @@ extern "C" int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched
                             int32_t res_w, int32_t res_h, int32_t tile_size, int64_t *D_host) {
     int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
     if (rc) return rc;
-    return bin_count(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, nullptr, 0.0f, D_host);
+    GS_REQUIRE(D_host, "gs_bin_count: D_host is NULL");
+    if ((rc = bin_count_begin(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, nullptr, 0.0f))) return rc;
+    return bin_count_end(ctx, D_host);
 }
 
 extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
@@ -761,15 +781,31 @@ extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched,
     return bin_fill(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, nullptr, 0.0f, D, keys, vals, ranges);
 }
 
-extern "C" int gs_bin_count_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
-                                   const float *centers, const float *colors, const float *opacities,
-                                   const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
-                                   float pixel_offset, int64_t *D_host) {
+extern "C" int gs_bin_count_culled_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched,
+                                         const int32_t *depths, const float *centers, const float *colors,
+                                         const float *opacities, const float *conics, int32_t res_w,
+                                         int32_t res_h, int32_t tile_size, float pixel_offset) {
     int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
     if (rc) return rc;
     const float4 *rec = nullptr;
     if ((rc = cull_records(ctx, N, centers, colors, opacities, conics, false, &rec))) return rc;
-    return bin_count(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, rec, pixel_offset, D_host);
+    return bin_count_begin(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, rec, pixel_offset);
+}
+
+extern "C" int gs_bin_count_end(gs_ctx *ctx, int64_t *D_host) {
+    GS_REQUIRE(ctx, "gs_bin_count_end: ctx is NULL");
+    return bin_count_end(ctx, D_host);
+}
+
+extern "C" int gs_bin_count_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                                   const float *centers, const float *colors, const float *opacities,
+                                   const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
+                                   float pixel_offset, int64_t *D_host) {
+    GS_REQUIRE(D_host, "gs_bin_count_culled: D_host is NULL");
+    int rc = gs_bin_count_culled_begin(ctx, N, tiles_touched, depths, centers, colors, opacities, conics, res_w,
+                                       res_h, tile_size, pixel_offset);
+    if (rc) return rc;
+    return bin_count_end(ctx, D_host);
 }
 
 extern "C" int gs_bin_fill_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,

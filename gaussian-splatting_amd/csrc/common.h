@@ -61,6 +61,8 @@ struct gs_ctx {
     gs_buf tile_scratch; // rasterize_tile shim staging
     gs_buf loss_partials; // f64[1024] per-block loss sums
     uint64_t *total_host = nullptr;   // pinned, 2 words
+    hipEvent_t count_event = nullptr; // recorded behind the copy of D into total_host (gs_bin_count*_begin)
+    int32_t count_pending_N = -1;     // N of a gs_bin_count*_begin whose gs_bin_count_end has not run
     // state carried from gs_bin_count to gs_bin_fill
     bool prof_on = false;
     uint32_t prof_mask = 0xFFFFFFFFu;         // kernel ids that are timed when prof_on (option profile_mask)

@@ -144,6 +144,7 @@ extern "C" int gs_ctx_destroy(gs_ctx *ctx) {
     for (gs_prof_span &sp : ctx->prof_spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }
     for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     if (ctx->total_host) (void)hipHostFree(ctx->total_host);
+    if (ctx->count_event) (void)hipEventDestroy(ctx->count_event);
     delete ctx;
     return GS_OK;
 }

@@ -74,6 +74,7 @@ class SplatPipeline:
         self.opacity_is_logit = bool(opacity_is_logit)
         self.stats = {}
         self._lanes = []
+        self._alts = []
 
     def lanes(self, n):
         """n (DeviceContext, torch stream) pairs for rendering independent views concurrently: each
@@ -82,6 +83,17 @@ class SplatPipeline:
         while len(self._lanes) < n:
             self._lanes.append((api.DeviceContext(self.ctx.device_index), torch.cuda.Stream(self.ctx.device)))
         return self._lanes[:n]
+
+    def alt_contexts(self, n):
+        """A second DeviceContext (workspace) per lane, main stream included: with two, a lane can
+        count the tiles of its next view while the current view's records are still in use."""
+        while len(self._alts) < n:
+            self._alts.append(api.DeviceContext(self.ctx.device_index))
+        return self._alts[:n]
+
+    def contexts(self):
+        """Every DeviceContext this pipeline launches on (for profiling)."""
+        return [self.ctx] + [c for c, _ in self._lanes] + list(self._alts)
 
     def export(self):
         """The current parameters as a host GaussianSet (float64 NumPy, the reference's dtypes)."""
@@ -119,6 +131,11 @@ class SplatPipeline:
         return pres
 
     def forward(self, view, want_keys=False, ctx=None, pre=None):
+        return self.forward_finish(self.forward_begin(view, ctx=ctx, pre=pre), want_keys=want_keys)
+
+    def forward_begin(self, view, ctx=None, pre=None):
+        """K1 (unless `pre` comes from preprocess_batch) and the launch of the tile count; the host
+        does not wait.  forward_finish(token) does the rest."""
         c = ctx or self.ctx
         c.sync_stream()
         N = self.N
@@ -131,16 +148,31 @@ class SplatPipeline:
                                       api._ptr(pre["centers"]), api._ptr(pre["depths"]), api._ptr(pre["colors"]),
                                       api._ptr(pre["conics"]), api._ptr(pre["clamped"]), api._ptr(pre["rect"]),
                                       api._ptr(pre["radii"]), null, null, null, null, null, null), "gs_preprocess")
-        cam, centers, depths, colors, conics = pre["cam"], pre["centers"], pre["depths"], pre["colors"], pre["conics"]
-        clamped, rect, radii = pre["clamped"], pre["rect"], pre["radii"]
         opac = pre.get("opac")
         if opac is None:
             opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
-        cull = (centers, colors, opac, conics, self.pixel_offset) if self.cull_tiles else None
-        binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size, self.tile_size,
-                                          want_keys=want_keys, cull=cull)
+        tok = dict(c=c, pre=pre, opac=opac, bin=None)
+        if self.cull_tiles:
+            tok["bin"] = api.bin_culled_begin(c, pre["rect"], pre["depths"], self.result_size, self.tile_size,
+                                              (pre["centers"], pre["colors"], opac, pre["conics"], self.pixel_offset))
+        return tok
+
+    def forward_finish(self, tok, want_keys=False, after_blend=None):
+        """Waits for the tile count, then sort -> K6.  after_blend() (if given) runs right after K6 is
+        enqueued: train_step uses it to launch the lane's NEXT count before this view's loss and K7."""
+        c, pre, opac = tok["c"], tok["pre"], tok["opac"]
+        c.sync_stream()
+        cam, centers, depths, colors, conics = pre["cam"], pre["centers"], pre["depths"], pre["colors"], pre["conics"]
+        clamped, rect, radii = pre["clamped"], pre["rect"], pre["radii"]
+        if tok["bin"] is not None:
+            binning = api.bin_culled_finish(tok["bin"], want_keys=want_keys)
+        else:
+            binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size, self.tile_size,
+                                              want_keys=want_keys)
         image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
                                                       self.pixel_offset)
+        if after_blend is not None:
+            after_blend()
         state = dict(ctx=c, cam=cam, depths=depths, centers=centers, colors=colors, conics=conics, clamped=clamped,
                      radii=radii, opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final)
         self.stats = dict(D=binning.D)
@@ -243,7 +275,7 @@ class Optimizer:
 
 
 def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,
-               k8_tail=None, k1_first=None):
+               k8_tail=None, k1_first=None, k8_early_lanes=None):
     """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
@@ -299,13 +331,31 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
         if len(mine) > first:
             pres += pipe.preprocess_batch([views[v] for v in mine[first:]])
             pre_ready = main.record_event()
-        done = []
-        for k, v in enumerate(mine):
+        # two workspaces per lane: the count of a lane's next view is launched right behind this view's
+        # K6, so its result is on the host long before the lane has finished K7 and the host never
+        # waits for a whole view (a lane's queue does not run dry between views)
+        alts = pipe.alt_contexts(n_lanes)
+        tokens = {}
+
+        def begin(k):
+            if k >= len(mine):
+                return
             ctx, stream = lanes[k % n_lanes]
+            if (k // n_lanes) & 1:
+                ctx = alts[k % n_lanes]
             with torch.cuda.stream(stream):
                 if k >= first:
                     stream.wait_event(pre_ready)
-                image, state = pipe.forward(views[v], ctx=ctx, pre=pres[k])
+                tokens[k] = pipe.forward_begin(views[mine[k]], ctx=ctx, pre=pres[k])
+
+        for k in range(min(n_lanes, len(mine))):
+            begin(k)
+        done = []
+        for k, v in enumerate(mine):
+            _, stream = lanes[k % n_lanes]
+            with torch.cuda.stream(stream):
+                image, state = pipe.forward_finish(tokens.pop(k), after_blend=lambda k=k: begin(k + n_lanes))
+                ctx = state["ctx"]
                 dL, _ = pipe.image_loss(image, targets[v], loss_kind, scale, losses[k:k + 1], ctx=ctx)
                 pipe.backward_rows(state, dL)
                 done.append(stream.record_event())
@@ -316,6 +366,26 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
                 pipe.backward_params(states[:early], grads, accumulate=False)
         if states_hook is not None:
             early = 0
+        # The lanes do not finish together (the hardware serves the queues in a fixed order): the
+        # views of the first k8_early_lanes lanes get their K8 on lane 0's stream as soon as they are
+        # complete, under the blend kernels of the lanes still running; the rest follow after the join.
+        if k8_early_lanes is None:
+            k8_early_lanes = n_lanes // 2 if main_is_lane else 0
+        early_set = [k for k in range(len(mine)) if k % n_lanes < k8_early_lanes]
+        if early == 0 and states_hook is None and 2 <= len(early_set) < len(mine):
+            ctx0, stream0 = lanes[0]
+            with torch.cuda.stream(stream0):
+                for k in early_set:
+                    stream0.wait_event(done[k])
+                pipe.backward_params([states[k] for k in early_set], grads, accumulate=False, ctx=ctx0)
+            late = [st for k, st in enumerate(states) if k not in set(early_set)]
+            for _, stream in lanes:
+                main.wait_stream(stream)
+            loss = losses.sum()
+            pipe.backward_params(late, grads, accumulate=True)
+            if distributed and world > 1:
+                dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
+            return loss, len(mine)
         for _, stream in lanes:
             main.wait_stream(stream)
     else:

@@ -120,6 +120,18 @@ int gs_bin_fill_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, con
                        const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
                        float pixel_offset, int64_t D, uint64_t *keys, int32_t *vals, int32_t *ranges);
 
+/* gs_bin_count_culled in two halves, for callers that keep several views in flight on one stream (no
+ * counterpart in the reference): _begin launches the count and records an event behind the copy of
+ * D to pinned memory; gs_bin_count_end waits for THAT event only -- work enqueued on the stream after
+ * _begin (another view's blend kernels on another ctx) keeps running -- and returns D.  One count
+ * may be pending per ctx; gs_bin_fill_culled follows gs_bin_count_end as it follows
+ * gs_bin_count_culled. */
+int gs_bin_count_culled_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                              const float *centers, const float *colors, const float *opacities,
+                              const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
+                              float pixel_offset);
+int gs_bin_count_end(gs_ctx *ctx, int64_t *D_host);
+
 /* Replaces gpu_rasterize forward (rasterization.py:27-107 + kernel rasterize,
  * setup_gpu.py:46-100), c_rasterize/rasterize_tile (rasterization.py:109-153, rasterize.c:27-132)
  * and rasterize (rasterization.py:155-215): one launch for the whole frame.
