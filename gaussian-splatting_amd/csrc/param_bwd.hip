@@ -41,7 +41,7 @@ struct BatchArgs {
 };
 
 #ifndef GS_K8_WAVES
-#define GS_K8_WAVES 1
+#define GS_K8_WAVES 2
 #endif
 template <bool ROWS>
 __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
@@ -75,25 +75,64 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
     const double sc[3] = {exp((double)log_scales[3 * i]), exp((double)log_scales[3 * i + 1]),
                           exp((double)log_scales[3 * i + 2])};
 
-#pragma unroll 1
-    for (int v = 0; v < args.n_views; v++) {
-        const ViewIn &V = args.v[v];
-        const PreCam &cam = V.cam;
-        if (V.radii[i] <= 0) continue;
-        any = true;
+    // The thread's 48 SH coefficients are needed once per view: a thread-private copy in LDS (no
+    // barrier: nobody else reads it) instead of 12 global loads per view that miss L1 at this
+    // occupancy.  [vv][thread] float4: conflict-free for both the write and the reads.
+    __shared__ float4 s_sh4[12][256];
+    {
+        const float4 *sh4 = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
+#pragma unroll
+        for (int vv = 0; vv < 12; vv++) s_sh4[vv][threadIdx.x] = sh4[vv];
+    }
 
-        float in_c[2], in_con[3], in_col[3];
+    // S', M = R S' and Sigma = M M^T do not depend on the view (scale_mod is a frame constant,
+    // checked on the host): once per gaussian (forward_pass.py:74-76)
+    const double sm = args.v[0].cam.scale_mod;
+    const double S[9] = {sc[0] * sm, sm, sm, sm, sc[1] * sm, sm, sm, sm, sc[2] * sm};
+    double M[9], Sg[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            M[3 * r + c] = R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c];
+    for (int r = 0; r < 3; r++)
+        for (int c = r; c < 3; c++)
+            Sg[3 * r + c] = Sg[3 * c + r] = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2];
+
+    // per-view inputs, fetched one view ahead of their use (two HBM round trips per view otherwise)
+    struct Inputs {
+        int radius;
+        float c[2], con[3], col[3], d_op;
+        bool clamp[3];
+    };
+    auto fetch = [&](int v) {
+        Inputs in;
+        const ViewIn &V = args.v[v];
+        in.radius = V.radii[i];
+        in.d_op = 0.0f;
         if (ROWS) {
             const float4 *r = reinterpret_cast<const float4 *>(V.rows + (size_t)i * 16);
             const float4 r0 = r[0], r1 = r[1];
-            in_c[0] = r0.x; in_c[1] = r0.y;
-            in_con[0] = r0.z; in_con[1] = r0.w; in_con[2] = r1.x;
-            g_op += r1.y;
-            in_col[0] = r1.z; in_col[1] = r1.w; in_col[2] = V.rows[(size_t)i * 16 + 8];
+            in.c[0] = r0.x; in.c[1] = r0.y;
+            in.con[0] = r0.z; in.con[1] = r0.w; in.con[2] = r1.x;
+            in.d_op = r1.y;
+            in.col[0] = r1.z; in.col[1] = r1.w; in.col[2] = V.rows[(size_t)i * 16 + 8];
         } else {
-            in_c[0] = V.d_centers[2 * i]; in_c[1] = V.d_centers[2 * i + 1];
-            for (int k = 0; k < 3; k++) { in_con[k] = V.d_conics[3 * i + k]; in_col[k] = V.d_colors[3 * i + k]; }
+            in.c[0] = V.d_centers[2 * i]; in.c[1] = V.d_centers[2 * i + 1];
+            for (int k = 0; k < 3; k++) { in.con[k] = V.d_conics[3 * i + k]; in.col[k] = V.d_colors[3 * i + k]; }
         }
+        for (int k = 0; k < 3; k++) in.clamp[k] = V.clamped[3 * i + k] != 0;
+        return in;
+    };
+    Inputs nxt = fetch(0);
+
+#pragma unroll 1
+    for (int v = 0; v < args.n_views; v++) {
+        const PreCam &cam = args.v[v].cam;
+        const Inputs in = nxt;
+        if (v + 1 < args.n_views) nxt = fetch(v + 1);
+        if (in.radius <= 0) continue;
+        any = true;
+        g_op += in.d_op;
+        const float *in_c = in.c, *in_con = in.con, *in_col = in.col;
 
         // ---- 2D centre <- world mean (quirk Q1: proj_mat on world coordinates)
         {
@@ -104,17 +143,8 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
             g_mean[2] += -dcx * (.5 * cam.W * cam.p00 * x * mw * mw) - dcy * (.5 * cam.H * cam.p11 * y * mw * mw);
         }
 
-        // ---- recompute S', M, Sigma, W rows, cov2d (forward_pass.py:74-86)
+        // ---- recompute the W rows and cov2d (forward_pass.py:78-86)
         const double tz = cam.Rt[6] * x + cam.Rt[7] * y + cam.Rt[8] * z + cam.t[2];
-        const double sm = cam.scale_mod;
-        const double S[9] = {sc[0] * sm, sm, sm, sm, sc[1] * sm, sm, sm, sm, sc[2] * sm};
-        double M[9], Sg[9];
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++)
-                M[3 * r + c] = R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c];
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++)
-                Sg[3 * r + c] = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2];
         const double j00 = cam.fx / tz, j11 = cam.fy / tz;
         const double W0[3] = {j00 * cam.Rt[0], j00 * cam.Rt[1], j00 * cam.Rt[2]};
         const double W1[3] = {j11 * cam.Rt[3], j11 * cam.Rt[4], j11 * cam.Rt[5]};
@@ -199,15 +229,14 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
             }
         }
         const int nb = (cam.degree + 1) * (cam.degree + 1);
-        const float4 *sh4 = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // dL/d(dir)
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const float dcol = V.clamped[3 * i + ch] ? 0.0f : in_col[ch];
+            const float dcol = in.clamp[ch] ? 0.0f : in_col[ch];
             float ex = 0.f, ey = 0.f, ez = 0.f;
 #pragma unroll
             for (int vv = 0; vv < 4; vv++) {
-                const float4 f = sh4[ch * 4 + vv];
+                const float4 f = s_sh4[ch * 4 + vv][threadIdx.x];
                 const float coef[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -232,13 +261,7 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
     }
 
     if (any) {
-        // ---- Sigma -> M: dM = (G + G^T) M, with any view's scale_mod (it is a frame constant)
-        const double sm = args.v[0].cam.scale_mod;
-        const double S[9] = {sc[0] * sm, sm, sm, sm, sc[1] * sm, sm, sm, sm, sc[2] * sm};
-        double M[9];
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++)
-                M[3 * r + c] = R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c];
+        // ---- Sigma -> M: dM = (G + G^T) M
         double dM[9];
         for (int r = 0; r < 3; r++)
             for (int cc = 0; cc < 3; cc++)
