@@ -665,3 +665,54 @@ def test_culled_binning_is_the_exact_list_minus_dead_pairs(gpu_ctx, tile, W, H, 
     for a, b_ in zip(ge, gc):
         scale = a.abs().max().item()
         assert (a - b_).abs().max().item() <= 1e-5 * scale
+
+
+def test_culled_binning_edge_cases_and_call_order(gpu_ctx):
+    """Empty input, opacity 0 / NaN records (never emitted), a NaN conic (kept: the test must not drop
+    what it cannot decide), and the begin / end / fill call order of the two-phase count."""
+    import ctypes
+    import torch
+    import gsplat_amd as gs
+    dev = gpu_ctx.device
+    rs = [64, 48]
+    f32 = torch.float32
+    e = lambda *shape: torch.zeros(shape, dtype=f32, device=dev)
+    b = gs.match_gaus_to_tiles(gpu_ctx, None, None, np.zeros((0, 2, 2), np.int32), np.zeros(0), np.zeros(0, np.int32),
+                               result_size=rs, cull=(e(0, 2), e(0, 3), e(0), e(0, 3), 0.5))
+    assert b.D == 0 and np.all(b.ranges.cpu().numpy() == 0)
+    # five gaussians over the whole 4x3 grid, centred in tile (1,1): a normal one, opacity 0, NaN opacity,
+    # a NaN conic, and one whose depth key is 0 (filtered like rasterization.py:67)
+    tt = np.tile(np.array([[[0, 0], [4, 3]]], dtype=np.int32), (5, 1, 1))
+    dep = np.array([5, 6, 7, 8, 0], dtype=np.int32)
+    cen = torch.tensor([[24.0, 24.0]] * 5, dtype=f32, device=dev)
+    col = torch.full((5, 3), 0.5, dtype=f32, device=dev)
+    opa = torch.tensor([0.8, 0.0, float("nan"), 0.8, 0.8], dtype=f32, device=dev)
+    con = torch.tensor([[0.5, 0.0, 0.5]] * 5, dtype=f32, device=dev)
+    con[3, 0] = float("nan")
+    b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, np.ones(5), dep, result_size=rs, cull=(cen, col, opa, con, 0.5))
+    vals = b.vals.cpu().numpy()
+    assert set(vals.tolist()) == {0, 3}                        # 1, 2 (no opacity) and 4 (depth 0) never appear
+    assert (vals == 3).sum() == 12                             # undecidable: every tile of its rect
+    # sigma = sqrt(2) px at (24,24): reaches 1/255 within ~4.6 px -> the four tiles around the corner (16..31)
+    assert 1 <= (vals == 0).sum() <= 4
+    exact = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, np.ones(5), dep, result_size=rs)
+    assert exact.D == 48
+    # call order: end without begin, fill without count, culled fill after a plain count
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    D = ctypes.c_int64(0)
+    assert lib.gs_bin_count_end(h, ctypes.byref(D)) < 0 and b"pending" in lib.gs_last_error()
+    rect = torch.tensor(tt.reshape(5, 4), device=dev)
+    depd = torch.tensor(dep, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.gs_bin_count(h, 5, p(rect), p(depd), 64, 48, 16, ctypes.byref(D)) == 0 and D.value == 48
+    vals_t = torch.empty(64, dtype=torch.int32, device=dev)
+    ranges_t = torch.empty((12, 2), dtype=torch.int32, device=dev)
+    rc = lib.gs_bin_fill_culled(h, 5, p(rect), p(depd), p(cen), p(col), p(opa), p(con), 64, 48, 16, 0.5, 48, None,
+                                p(vals_t), p(ranges_t))
+    assert rc < 0 and b"gs_bin_count first" in lib.gs_last_error()
+    assert lib.gs_bin_count_culled_begin(h, 5, p(rect), p(depd), p(cen), p(col), p(opa), p(con), 64, 48, 16, 0.5) == 0
+    assert lib.gs_bin_count_end(h, ctypes.byref(D)) == 0 and D.value == b.D
+    assert lib.gs_bin_fill_culled(h, 5, p(rect), p(depd), p(cen), p(col), p(opa), p(con), 64, 48, 16, 0.5, D.value,
+                                  None, p(vals_t), p(ranges_t)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(vals_t[:D.value].cpu().numpy(), vals) and np.array_equal(ranges_t.cpu().numpy(), b.ranges.cpu().numpy())
