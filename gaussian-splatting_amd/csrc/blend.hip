@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
             const float4 co = s_con[j];
             const int idx = __float_as_int(co.w);
             const float4 rgb = s_rgb[j];
-            float s_x = 0.f, s_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+            float s_x = 0.f, s_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_q = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
             bool any_valid = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -702,10 +702,12 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                 g_r = __builtin_fmaf(w, dLp[k][0], g_r);
                 g_g = __builtin_fmaf(w, dLp[k][1], g_g);
                 g_b = __builtin_fmaf(w, dLp[k][2], g_b);
-                // min(.99, .) passes no gradient where the clamp is active
-                const float dm = (valid && !(araw > ALPHA_MAX)) ? dLda : 0.0f;
-                g_o = __builtin_fmaf(G, dm, g_o);
-                const float q = araw * dm;                 // dL/dG * G
+                // q = dL/dG * G = opacity*G * dL/dalpha.  av is 0 on the lanes that skip this gaussian (and dLda
+                // is finite there), so no select on validity is needed -- and none may multiply G itself, which
+                // is +inf where an indefinite conic drives the power far above 0.  min(.99, .) passes no
+                // gradient where the clamp is active.
+                const float q = (araw > ALPHA_MAX) ? 0.0f : av * dLda;
+                g_q += q;                                  // dL/dopacity = sum(G dL/dalpha) = sum(q) / opacity
                 const float qx = q * dx, qy = q * dy;
                 s_x += qx;
                 s_y += qy;
@@ -720,6 +722,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
             // d power2/d cx = 2a' dx + b' dy and d power2/d cy = 2c' dy + b' dx, with (a', b', c') uniform
             float g_cx = __builtin_fmaf(co.x + co.x, s_x, co.y * s_y);
             float g_cy = __builtin_fmaf(co.z + co.z, s_y, co.y * s_x);
+            float g_o = g_q * __builtin_amdgcn_rcpf(ge.z);    // opacity > 0: the others are dropped at staging
             swap32(g_cx, g_A); const float w0 = g_cx + g_A;
             swap32(g_cy, g_B); const float w1 = g_cy + g_B;
             swap32(g_C, g_r);  const float w2 = g_C + g_r;

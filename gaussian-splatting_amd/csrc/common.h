@@ -104,11 +104,14 @@ int gs_pack_records(gs_ctx *ctx, int32_t N, const float *centers, const float *c
 
 // max over the pixel box [xlo,xhi]x[ylo,yhi] of power2 >= tau ?  u = cx - x in [ulo,uhi], v likewise.
 // Q = alpha u^2 + beta u v + gamma v^2 is convex; outside the origin its box minimum lies on one
-// of the four edges.  NaNs (degenerate conics) fall through to "keep".
+// of the four edges.  Conics that are not positive definite, NaNs included, are kept undecided.
 __device__ __forceinline__ bool gs_box_may_contribute(const float4 geo, const float4 con, float xlo, float xhi,
                                                       float ylo, float yhi) {
     const float ulo = geo.x - xhi, uhi = geo.x - xlo, vlo = geo.y - yhi, vhi = geo.y - ylo;
     const float al = -con.x, be = -con.y, ga = -con.z;
+    if (geo.w >= 1e29f) return false;        // opacity <= 0 or NaN (tau = 1e30): alpha never reaches 1/255
+    // not positive definite (or NaN): the edge minima below assume convexity -> undecided, keep
+    if (!(al > 0.0f && ga > 0.0f && be * be < 4.0f * al * ga)) return true;
     float qmin;
     if (ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f) {
         qmin = 0.0f;

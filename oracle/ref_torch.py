@@ -132,7 +132,9 @@ def blend(centers, colors, opacities, conics, vals, ranges, result_size, tile_si
         dy = centers[g, 1][:, None] - py + pixel_offset
         cn = conics[g]
         power = -.5 * (cn[:, 0:1] * dx * dx + cn[:, 2:3] * dy * dy) - cn[:, 1:2] * dx * dy
-        alpha = torch.clamp(opacities[g][:, None] * torch.exp(power), max=.99)
+        # pairs with power > 0 are skipped below; clamping keeps exp() finite there so that autograd does not
+        # turn their masked-out branch into 0 * inf = NaN (indefinite conics)
+        alpha = torch.clamp(opacities[g][:, None] * torch.exp(torch.clamp(power, max=0.0)), max=.99)
         active = has[:, None] & ~done & ~(power > 0) & ~(alpha < (1.0 / 255))
         test_T = T * (1.0 - alpha)
         brk = active & (test_T < .0001)

@@ -716,3 +716,97 @@ def test_culled_binning_edge_cases_and_call_order(gpu_ctx):
                                   None, p(vals_t), p(ranges_t)) == 0
     torch.cuda.synchronize()
     assert np.array_equal(vals_t[:D.value].cpu().numpy(), vals) and np.array_equal(ranges_t.cpu().numpy(), b.ranges.cpu().numpy())
+
+
+def _adversarial_2d(seed, W, H):
+    """2D blend inputs built to sit on the decisions of the blend kernels: opacity 0 / below, at and above
+    1/255 / at and above the .99 clamp, sub-pixel and frame-sized footprints, near-singular, indefinite and
+    negative conics (power > 0, rasterize.c:109), an almost flat one, centres on tile corners and outside the frame."""
+    rng = np.random.default_rng(seed)
+    cen, con, opa = [], [], []
+    corners = [(16.0, 16.0), (15.5, 31.5), (32.0, 48.0), (47.5, 16.5), (-20.0, 10.0), (W + 30.0, H / 2), (W / 2, -40.0)]
+    for _ in range(220):
+        kind = rng.integers(0, 8)
+        c = corners[rng.integers(len(corners))] if rng.random() < 0.3 else (rng.uniform(-10, W + 10), rng.uniform(-10, H + 10))
+        sx, sy = np.exp(rng.uniform(np.log(0.3), np.log(60.0), 2))
+        th = rng.uniform(0, np.pi)
+        if kind == 0:
+            sx, sy = 0.25, 0.3                                   # sub-pixel
+        if kind == 1:
+            sx, sy = 150.0, 220.0                                # frame-sized
+        if kind == 2:
+            sx, sy = 80.0, 0.4                                   # needle: conic close to singular after rotation
+        Rm = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        cov = Rm @ np.diag([sx * sx, sy * sy]) @ Rm.T
+        inv = np.linalg.inv(cov)
+        A, B, C = inv[0, 0], inv[0, 1], inv[1, 1]
+        if kind == 3:
+            B = np.sign(B if B else 1.0) * np.sqrt(A * C) * 1.05  # indefinite: power > 0 in two sectors
+        if kind == 4:
+            A = -abs(A) * 0.1                                     # negative along x
+        if kind == 5:
+            A, B, C = 2e-6, 0.0, 1e-6                             # almost flat: alpha ~ opacity over the whole frame
+        o = [0.0, 1 / 300, 1 / 255, 0.0040, 0.3, 0.8, 0.99, 1.0][rng.integers(0, 8)]
+        cen.append(c); con.append((A, B, C)); opa.append(o)
+    n = len(cen)
+    col = rng.uniform(0, 1, (n, 3))
+    return (np.asarray(cen, np.float32), col.astype(np.float32), np.asarray(opa, np.float32), np.asarray(con, np.float32))
+
+
+@pytest.mark.parametrize("seed,tile", [(1, 16), (2, 16), (3, 32)])
+def test_blend_adversarial_inputs_vs_oracles(gpu_ctx, seed, tile):
+    """K6/K7 on inputs placed on their decision boundaries, every gaussian listed in every tile: image,
+    last contributors and T_final against the C restatement (reference's lists), the culled lists give the
+    same image, gradients against fp64 autograd of the restated blend."""
+    import torch
+    import gsplat_amd as gs
+    W, H = 96, 80
+    cen, col, opa, con = _adversarial_2d(seed, W, H)
+    n = len(cen)
+    rs = [W, H]
+    tx_n, ty_n = -(-W // tile), -(-H // tile)
+    tt = np.tile(np.array([[[0, 0], [tx_n, ty_n]]], dtype=np.int32), (n, 1, 1))
+    dep = np.random.default_rng(seed).permutation(n).astype(np.int32) + 1
+    bg = np.array([0.2, 0.4, 0.1])
+    dev = gpu_ctx.device
+    t = lambda a: torch.tensor(a, device=dev)
+    exact = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, np.ones(n), dep, result_size=rs, tile_size=tile)
+    assert exact.D == n * tx_n * ty_n
+    culled = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, np.ones(n), dep, result_size=rs, tile_size=tile,
+                                    cull=(t(cen), t(col), t(opa), t(con), 0.5))
+    assert culled.D < exact.D
+    bg3 = gs.api._bg3(bg)
+    img, nc, tf = gs.api.blend_forward(gpu_ctx, t(cen), t(col), t(opa), t(con), exact, bg3, 0.5)
+    img_c, nc_c, tf_c = gs.api.blend_forward(gpu_ctx, t(cen), t(col), t(opa), t(con), culled, bg3, 0.5)
+    assert torch.equal(img, img_c) and torch.equal(tf, tf_c)
+    # every gaussian is listed in every tile, so the tile-16 lists describe the same blend whatever `tile` is
+    t16 = np.tile(np.array([[[0, 0], [W // 16, H // 16]]], dtype=np.int32), (n, 1, 1))
+    e16 = exact if tile == 16 else gs.match_gaus_to_tiles(gpu_ctx, None, None, t16, np.ones(n), dep, result_size=rs)
+    ref, lc, tfr, fragile, _ = cref.rasterize_frame(cen, col, opa, con, e16.vals.cpu().numpy(),
+                                                    e16.ranges.cpu().numpy(), rs, bg, pixel_offset=0.5, margin=1e-4)
+    ok = ~fragile.astype(bool)
+    assert fragile.mean() < 0.35                            # the inputs sit on the discontinuities on purpose
+    got = img.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(got - ref)[ok] <= IMG_ATOL + IMG_RTOL * np.abs(ref)[ok])
+    np.testing.assert_allclose(tf.cpu().numpy()[ok], tfr[ok], rtol=1e-4, atol=1e-7)
+    if tile == 16:
+        assert np.array_equal((nc.cpu().numpy() & 0x7FFFFFFF)[ok], lc[ok])
+    # gradients: fp64 autograd of the restated blend over the same lists
+    rng = np.random.default_rng(seed + 10)
+    wimg = rng.normal(size=(W, H, 3)).astype(np.float32)
+    p = [torch.tensor(a.astype(np.float64), requires_grad=True) for a in (cen, col, opa, con)]
+    ref_img = ref_torch.blend(p[0], p[1], p[2], p[3], exact.vals.cpu().numpy(), exact.ranges.cpu().numpy(), rs, tile,
+                              bg, 0.5)
+    (ref_img * torch.tensor(wimg, dtype=torch.float64)).sum().backward()
+    assert np.abs(ref_img.detach().numpy() - ref)[ok].max() < 1e-9      # the two oracles agree
+    for binning, state in ((exact, (nc, tf)), (culled, (nc_c, tf_c))):
+        d_cen, d_con, d_opa, d_col = gs.api.blend_backward(gpu_ctx, t(cen), t(col), t(opa), t(con), binning, bg3, 0.5,
+                                                           state[0], state[1], t(wimg))
+        for got, want, what in ((d_cen, p[0].grad, "centers"), (d_col, p[1].grad, "colors"), (d_opa, p[2].grad, "opacity"),
+                                (d_con, p[3].grad, "conics")):
+            g, w = got.cpu().numpy().astype(np.float64), want.numpy()
+            assert np.all(np.isfinite(g)), what
+            # branch flips at the placed discontinuities move single pixels: a few per cent of the largest entry
+            assert np.abs(g - w).max() <= 0.05 * np.abs(w).max(), (what, np.abs(g - w).max(), np.abs(w).max())
+            close = np.abs(g - w) <= 2e-3 * np.abs(w).max()
+            assert close.mean() > 0.9, (what, close.mean())
