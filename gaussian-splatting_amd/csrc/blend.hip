@@ -402,6 +402,7 @@ constexpr int QUAD_WAVES = 4;
 // Diagnostic build only (-DGS_STAMPS, tools/stamp_blend.py): per-wave start/end times and placement,
 // written to a buffer nothing else reads.  No stamp executes in the product build.
 #ifdef GS_STAMPS
+__device__ unsigned long long gs_valid_hist[16];   // K7: reduced entries by number of valid pixels (log2 buckets)
 constexpr int STAMP_TILES = 65536;
 __device__ unsigned long long gs_stamps[2][STAMP_TILES][4];
 #define GS_STAMP_BEGIN() const unsigned long long stamp_t0_ = __builtin_amdgcn_s_memrealtime()
@@ -677,6 +678,9 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
             const float4 rgb = s_rgb[j];
             float s_x = 0.f, s_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_q = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
             bool any_valid = false;
+#ifdef GS_STAMPS
+            int n_valid_px = 0;
+#endif
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (!((live[k] >> j) & 1ull)) continue;     // scalar test
@@ -690,6 +694,9 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                 const bool valid = idx < end_k[k] && p <= 0.0f && !(alpha < ALPHA_MIN);
                 if (!wave_any(valid)) continue;
                 any_valid = true;
+#ifdef GS_STAMPS
+                n_valid_px += __popcll(__ballot(valid));
+#endif
                 // lanes that skip this gaussian run with alpha = 0: inv = 1, T unchanged, w = 0
                 const float av = valid ? alpha : 0.0f;
                 const float inv = __builtin_amdgcn_rcpf(1.0f - av);
@@ -716,6 +723,9 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                 g_C = __builtin_fmaf(qy, dy, g_C);
             }
             if (!any_valid) continue;    // wave-uniform
+#ifdef GS_STAMPS
+            if (lane == 0) atomicAdd(&gs_valid_hist[32 - __builtin_clz((unsigned)n_valid_px)], 1ull);
+#endif
             // 9 wave-wide sums in 6 lane swaps + 6 adds + 14 DPP adds instead of 54 DPP adds (a DPP add
             // issues in 4 cycles, twice a plain VALU op): permlane32/16 swaps fold two values per
             // instruction, leaving each 16-lane row with its own pair of values to finish.
@@ -754,6 +764,9 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
 }
 
 #ifdef GS_STAMPS
+extern "C" int gs_debug_read_valid_hist(unsigned long long *host16) {
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(gs_valid_hist), 16 * 8, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int gs_debug_read_stamps(int which, unsigned long long *host, int ntiles) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gs_stamps), (size_t)ntiles * 32, (size_t)which * STAMP_TILES * 32,
                                     hipMemcpyDeviceToHost);

@@ -37,6 +37,11 @@ def run():
         image, st = pipe.forward(views[v])
         pipe.backward(st, (image - target) * 1e-6, grads)
     torch.cuda.synchronize()
+    hist = np.zeros(16, dtype=np.uint64)
+    lib.gs_debug_read_valid_hist.argtypes = [ctypes.c_void_p]
+    assert lib.gs_debug_read_valid_hist(hist.ctypes.data) == 0
+    tot = hist.sum()
+    print("K7 reduced entries by valid pixels (2 views):", {f"<{1 << b}": f"{int(hist[b])} ({hist[b] / tot:.1%})" for b in range(1, 10) if hist[b]})
     ntiles = 120 * 68
     for which, name in ((0, "forward"), (1, "backward")):
         buf = np.zeros((ntiles, 4), dtype=np.uint64)
