@@ -25,6 +25,11 @@ class GsViewPreprocess(ctypes.Structure):
                 ("centers", "depths", "colors", "conics", "clamped", "tiles_touched", "radii")]
 
 
+class GsViewRecords(ctypes.Structure):
+    _fields_ = [("cam", ctypes.POINTER(GsCamera))] + [(n, ctypes.c_void_p) for n in
+                ("records", "depths", "clamped", "tiles_touched", "radii")]
+
+
 class GsError(RuntimeError):
     pass
 
@@ -48,6 +53,8 @@ SIGNATURES = {
     "gs_version": (ctypes.c_int, []),
     "gs_preprocess": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, ctypes.POINTER(GsCamera)] + [_P] * 13),
     "gs_preprocess_batch": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _I32, ctypes.POINTER(GsViewPreprocess)]),
+    "gs_preprocess_batch_records": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, ctypes.POINTER(GsViewRecords)]),
+    "gs_ctx_use_records": (ctypes.c_int, [_P, _I32, _P]),
     "gs_bin_count": (ctypes.c_int, [_P, _I32, _P, _P, _I32, _I32, _I32, ctypes.POINTER(_I64)]),
     "gs_bin_fill": (ctypes.c_int, [_P, _I32, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P]),
     "gs_bin_count_culled": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float,

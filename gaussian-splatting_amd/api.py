@@ -333,9 +333,12 @@ def bin_culled_begin(ctx, tiles_touched, depths, result_size, tile_size, cull):
     dep = _dev(depths, torch.int32, dev, (N,))
     W, H, ts = int(result_size[0]), int(result_size[1]), int(tile_size)
     cen, col, opa, con, off = cull
-    held = (_dev(cen, torch.float32, dev, (N, 2)), _dev(col, torch.float32, dev, (N, 3)),
-            _dev(opa, torch.float32, dev, (N,)), _dev(con, torch.float32, dev, (N, 3)))
-    extra = tuple(_ptr(t) for t in held)
+    if cen is None:      # the ctx has been given records (gs_ctx_use_records): the four arrays are not read
+        held, extra = (), (_ptr(None),) * 4
+    else:
+        held = (_dev(cen, torch.float32, dev, (N, 2)), _dev(col, torch.float32, dev, (N, 3)),
+                _dev(opa, torch.float32, dev, (N,)), _dev(con, torch.float32, dev, (N, 3)))
+        extra = tuple(_ptr(t) for t in held)
     check(c.lib.gs_bin_count_culled_begin(c.handle, N, _ptr(rect), _ptr(dep), *extra, W, H, ts, float(off)),
           "gs_bin_count_culled_begin")
     return dict(c=c, N=N, rect=rect, dep=dep, held=held, extra=extra, W=W, H=H, ts=ts, off=float(off))
@@ -396,7 +399,7 @@ def blend_forward(c, centers, colors, opacities, conics, binning, bg, pixel_offs
     """Device tensors in, (image[W,H,3], n_contrib[W,H], t_final[W,H]) out."""
     dev = c.device
     W, H = binning.result_size
-    N = centers.shape[0]
+    N = opacities.shape[0]
     image = torch.empty((W, H, 3), dtype=torch.float32, device=dev)
     n_contrib = torch.empty((W, H), dtype=torch.int32, device=dev)
     t_final = torch.empty((W, H), dtype=torch.float32, device=dev)

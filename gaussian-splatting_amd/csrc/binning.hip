@@ -756,8 +756,6 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
 
 int cull_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,
                  const float *conics, bool reuse, const float4 **rec) {
-    GS_REQUIRE(N == 0 || (centers && colors && opacities && conics), "gs_bin_*_culled: NULL gaussian array");
-    GS_REQUIRE(((uintptr_t)centers & 7) == 0, "gs_bin_*_culled: centers must be 8-byte aligned");
     GS_HIP(hipSetDevice(ctx->device));
     return gs_pack_records(ctx, N, centers, colors, opacities, conics, reuse, rec);
 }

@@ -340,9 +340,7 @@ __global__ __launch_bounds__(256 / PPT) void blend_bwd_kernel(BlendArgs a, const
 // over the tile's pixel box) and the batch is compacted with a ballot; skipped entries change no
 // pixel, and `last_contributors` keeps counting them because every staged entry carries its
 // original list index.
-constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr float TAU_MARGIN = 0.02f;    // log2 units: 1.4 % in alpha, far above fp32 error
 
 // one 64-byte record per gaussian, so that staging an entry touches ONE cache line:
 //   [0] geo = cx, cy, opacity, tau
@@ -366,17 +364,12 @@ __global__ __launch_bounds__(256) void pack_kernel(int N, const float2 *__restri
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 2, part = t & 3;
     if (i >= N) return;
-    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (part == 0) {
-        const float2 c = centers[i];
-        const float o = opacities[i];
-        const float tau = (o > 0.0f) ? (__log2f(ALPHA_MIN / o) - TAU_MARGIN) : 1e30f;
-        v = make_float4(c.x, c.y, o, tau);
-    } else if (part == 1) {
-        v = make_float4(-0.5f * LOG2E * conics[3 * i], -LOG2E * conics[3 * i + 1], -0.5f * LOG2E * conics[3 * i + 2], 0.0f);
-    } else if (part == 2) {
-        v = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.0f);
-    }
+    // every thread of the four builds the record (a few loads from the same lines) and keeps its quarter
+    float4 geo, con, rgb;
+    const float2 c = centers[i];
+    gs_make_record(c.x, c.y, opacities[i], conics[3 * i], conics[3 * i + 1], conics[3 * i + 2], colors[3 * i],
+                   colors[3 * i + 1], colors[3 * i + 2], geo, con, rgb);
+    const float4 v = part == 0 ? geo : part == 1 ? con : part == 2 ? rgb : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     rec[t] = v;
 }
 
@@ -816,7 +809,8 @@ int fill_args(BlendArgs &a, gs_ctx *ctx, int32_t N, const float *centers, const 
     GS_REQUIRE(res_w > 0 && res_h > 0, "gs_blend: invalid frame %dx%d", res_w, res_h);
     GS_REQUIRE(N >= 0 && D >= 0, "gs_blend: negative N or D");
     GS_REQUIRE(ranges && bg, "gs_blend: ranges/background is NULL");
-    GS_REQUIRE(D == 0 || (centers && colors && opacities && conics && vals), "gs_blend: NULL array argument");
+    GS_REQUIRE(D == 0 || vals, "gs_blend: vals is NULL");
+    GS_REQUIRE(D == 0 || ctx->ext_records || (centers && colors && opacities && conics), "gs_blend: NULL array argument");
     GS_REQUIRE(((uintptr_t)centers & 7) == 0 && ((uintptr_t)ranges & 7) == 0,
                "gs_blend: centers and ranges must be 8-byte aligned");
     a.centers = reinterpret_cast<const float2 *>(centers);
@@ -833,6 +827,14 @@ int fill_args(BlendArgs &a, gs_ctx *ctx, int32_t N, const float *centers, const 
 
 int gs_pack_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,
                     const float *conics, bool reuse, const float4 **rec_out) {
+    if (ctx->ext_records) {      // gs_ctx_use_records: the caller's records stand in for the four arrays
+        GS_REQUIRE(ctx->ext_records_N == N, "gs_ctx_use_records was given N=%d, this call has N=%d",
+                   ctx->ext_records_N, N);
+        *rec_out = ctx->ext_records;
+        return GS_OK;
+    }
+    GS_REQUIRE(N == 0 || (centers && colors && opacities && conics), "NULL per-gaussian array (and no gs_ctx_use_records)");
+    GS_REQUIRE(((uintptr_t)centers & 7) == 0, "centers must be 8-byte aligned");
     int rc = gs_buf_reserve(ctx, &ctx->packed, (size_t)(N > 0 ? N : 1) * 64);
     if (rc) return rc;
     float4 *rec = (float4 *)ctx->packed.p;

@@ -75,6 +75,8 @@ struct gs_ctx {
     // arrays the packed blend records were built from (gs_blend_forward -> gs_blend_backward reuse)
     const void *packed_key[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t packed_N = -1;
+    const float4 *ext_records = nullptr;   // gs_ctx_use_records: caller-owned records replace ctx->packed
+    int32_t ext_records_N = -1;
     bool packed_fresh = false;   // gs_bin_fill_culled packed them: the next gs_blend_forward may reuse them
     bool bin_culled = false;     // gs_bin_count_culled produced bin_N / bin_D
 };
@@ -97,6 +99,19 @@ static inline int gs_div_up(int a, int b) { return (a + b - 1) / b; }
 //   [0] geo = cx, cy, opacity, tau     tau = log2(1/255 / opacity) - margin
 //   [1] con = a', b', c', 0            log2-scaled: power2 = a' dx^2 + b' dx dy + c' dy^2
 //   [2] rgb = r, g, b, 0               [3] zero
+constexpr float GS_LOG2E = 1.4426950408889634f;
+constexpr float GS_ALPHA_MIN = 1.0f / 255.0f;   // rasterize.c:114
+constexpr float GS_TAU_MARGIN = 0.02f;          // log2 units: 1.4 % in alpha, far above fp32 error
+
+// the one place that defines a record (pack_kernel and the record-writing form of K1 both call it)
+__device__ __forceinline__ void gs_make_record(float cx, float cy, float o, float A, float B, float C, float r,
+                                               float g, float b, float4 &geo, float4 &con, float4 &rgb) {
+    const float tau = (o > 0.0f) ? (__log2f(GS_ALPHA_MIN / o) - GS_TAU_MARGIN) : 1e30f;
+    geo = make_float4(cx, cy, o, tau);
+    con = make_float4(-0.5f * GS_LOG2E * A, -GS_LOG2E * B, -0.5f * GS_LOG2E * C, 0.0f);
+    rgb = make_float4(r, g, b, 0.0f);
+}
+
 // Packs the four arrays into ctx->packed on ctx->stream unless `reuse` and the same arrays were
 // packed last; *rec gets the record array.
 int gs_pack_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,

@@ -205,6 +205,7 @@ struct ViewOut {
     float *centers, *colors, *conics;
     int32_t *depths, *tiles_touched, *radii;
     uint8_t *clamped;
+    float4 *records;     // record-writing form: replaces centers / colors / conics
 };
 
 __device__ __forceinline__ void store_view(int i, const ViewOut &w, const PreOut &o) {
@@ -251,20 +252,38 @@ struct PreBatch {
     int n_views;
 };
 
+// RECORDS: instead of centers / colors / conics each view gets the 64-byte blend records (common.h) the
+// blend and culled-binning kernels read, built from the activated opacities: no pack pass per view.
+template <bool RECORDS>
 __global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const float *__restrict__ means,
                                                                const float *__restrict__ log_scales,
                                                                const float *__restrict__ quats,
-                                                               const float *__restrict__ sh, const PreBatch b) {
+                                                               const float *__restrict__ sh,
+                                                               const float *__restrict__ opacities, const PreBatch b) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     double x, y, z, q[4];
     float ls[3], coef[48];
     load_params(i, means, log_scales, quats, sh, x, y, z, q, ls, coef);
+    const float opac = RECORDS ? opacities[i] : 0.0f;
 #pragma unroll 1
     for (int v = 0; v < b.n_views; v++) {
         PreOut o;
         preprocess_one<false>(b.cam[v], x, y, z, q[0], q[1], q[2], q[3], ls, coef, o);
-        store_view(i, b.out[v], o);
+        if (RECORDS) {
+            const ViewOut &w = b.out[v];
+            w.depths[i] = o.depth;
+            w.radii[i] = o.rad;
+            reinterpret_cast<int4 *>(w.tiles_touched)[i] = make_int4(o.rect[0], o.rect[1], o.rect[2], o.rect[3]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) w.clamped[3 * i + k] = o.cl[k];
+            float4 geo, con, rgb;
+            gs_make_record(o.cx, o.cy, opac, o.con[0], o.con[1], o.con[2], o.col[0], o.col[1], o.col[2], geo, con, rgb);
+            float4 *r = w.records + (size_t)i * 4;
+            r[0] = geo; r[1] = con; r[2] = rgb; r[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            store_view(i, b.out[v], o);
+        }
     }
 }
 
@@ -348,10 +367,49 @@ extern "C" int gs_preprocess_batch(gs_ctx *ctx, int32_t N, const float *means, c
         for (int v = 0; v < b.n_views; v++) {
             const gs_view_preprocess &w = views[done + v];
             gs_make_precam(w.cam, &b.cam[v]);
-            b.out[v] = ViewOut{w.centers, w.colors, w.conics, w.depths, w.tiles_touched, w.radii, w.clamped};
+            b.out[v] = ViewOut{w.centers, w.colors, w.conics, w.depths, w.tiles_touched, w.radii, w.clamped, nullptr};
         }
-        { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_batch_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
-                           means, log_scales, quats, sh, b); }
+        { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_batch_kernel<false>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+                           means, log_scales, quats, sh, (const float *)nullptr, b); }
+        GS_HIP(hipGetLastError());
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_preprocess_batch_records(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                                           const float *quats, const float *sh, const float *opacities,
+                                           int32_t n_views, const gs_view_records *views) {
+    GS_REQUIRE(ctx, "gs_preprocess_batch_records: ctx is NULL");
+    GS_REQUIRE(N >= 0 && n_views >= 0, "gs_preprocess_batch_records: negative N or n_views");
+    GS_REQUIRE(n_views == 0 || views, "gs_preprocess_batch_records: views is NULL");
+    if (N == 0 || n_views == 0) return GS_OK;
+    GS_REQUIRE(means && log_scales && quats && sh && opacities, "gs_preprocess_batch_records: NULL parameter array");
+    GS_REQUIRE(((uintptr_t)sh & 15) == 0, "gs_preprocess_batch_records: sh must be 16-byte aligned");
+    for (int v = 0; v < n_views; v++) {
+        const gs_view_records &w = views[v];
+        GS_REQUIRE(w.cam, "gs_preprocess_batch_records: view %d has no camera", v);
+        GS_REQUIRE(w.cam->sh_degree >= 0 && w.cam->sh_degree <= 3, "gs_preprocess_batch_records: sh_degree %d not in 0..3",
+                   w.cam->sh_degree);
+        GS_REQUIRE(w.cam->res_w > 0 && w.cam->res_h > 0 && w.cam->tile_size > 0 && w.cam->cam_width > 0 &&
+                       w.cam->cam_height > 0 && w.cam->fx > 0 && w.cam->fy > 0,
+                   "gs_preprocess_batch_records: invalid camera/frame description in view %d", v);
+        GS_REQUIRE(w.records && w.depths && w.clamped && w.tiles_touched && w.radii,
+                   "gs_preprocess_batch_records: view %d has a NULL output", v);
+        GS_REQUIRE(((uintptr_t)w.tiles_touched & 15) == 0 && ((uintptr_t)w.records & 15) == 0,
+                   "gs_preprocess_batch_records: tiles_touched and records must be 16-byte aligned");
+    }
+    GS_HIP(hipSetDevice(ctx->device));
+    for (int done = 0; done < n_views; done += MAX_PRE_VIEWS) {
+        PreBatch b;
+        b.n_views = n_views - done < MAX_PRE_VIEWS ? n_views - done : MAX_PRE_VIEWS;
+        for (int v = 0; v < b.n_views; v++) {
+            const gs_view_records &w = views[done + v];
+            gs_make_precam(w.cam, &b.cam[v]);
+            b.out[v] = ViewOut{nullptr, nullptr, nullptr, w.depths, w.tiles_touched, w.radii, w.clamped,
+                               reinterpret_cast<float4 *>(w.records)};
+        }
+        { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_batch_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+                           means, log_scales, quats, sh, opacities, b); }
         GS_HIP(hipGetLastError());
     }
     return GS_OK;

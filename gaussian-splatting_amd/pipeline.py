@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import api
-from ._lib import GsViewBackward, GsViewPreprocess, check
+from ._lib import GsViewRecords, GsViewBackward, GsViewPreprocess, check
 
 GRAD_FLOATS = 59   # 3 mean + 3 log-scale + 4 quaternion + 1 opacity + 48 SH
 
@@ -110,13 +110,36 @@ class SplatPipeline:
                     clamped=torch.empty((N, 3), dtype=torch.uint8, device=dev),
                     rect=torch.empty((N, 4), dtype=i32, device=dev), radii=torch.empty((N,), dtype=i32, device=dev))
 
-    def preprocess_batch(self, views, ctx=None):
-        """K1 for several views in one pass over the parameters (gs_preprocess_batch); returns one
-        record per view to hand to forward(view, pre=...)."""
+    def preprocess_batch(self, views, ctx=None, records=None):
+        """K1 for several views in one pass over the parameters; returns one record per view to hand to
+        forward(view, pre=...).  records=True (default when tiles are culled): gs_preprocess_batch_records
+        writes each view's 64-byte blend records instead of centers / colors / conics, so no pack pass
+        runs per view (the per-view arrays are then None)."""
         c = ctx or self.ctx
         c.sync_stream()
-        pres = [self._alloc_pre(api.make_camera(v.camera, v.camera_r, v.camera_t, self.result_size, self.tile_size,
-                                                self.degrees)) for v in views]
+        records = self.cull_tiles if records is None else bool(records)
+        opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity   # once for the batch
+        cams = [api.make_camera(v.camera, v.camera_r, v.camera_t, self.result_size, self.tile_size, self.degrees)
+                for v in views]
+        if records:
+            dev, N, i32 = self.ctx.device, self.N, torch.int32
+            pres = [dict(cam=cam, centers=None, colors=None, conics=None,
+                         rec=torch.empty((N, 16), dtype=torch.float32, device=dev),
+                         depths=torch.empty((N,), dtype=i32, device=dev),
+                         clamped=torch.empty((N, 3), dtype=torch.uint8, device=dev),
+                         rect=torch.empty((N, 4), dtype=i32, device=dev), radii=torch.empty((N,), dtype=i32, device=dev),
+                         opac=opac) for cam in cams]
+            arr = (GsViewRecords * max(len(pres), 1))()
+            for k, p in enumerate(pres):
+                arr[k].cam = ctypes.pointer(p["cam"])
+                for name, key in (("records", "rec"), ("depths", "depths"), ("clamped", "clamped"),
+                                  ("tiles_touched", "rect"), ("radii", "radii")):
+                    setattr(arr[k], name, p[key].data_ptr())
+            check(c.lib.gs_preprocess_batch_records(c.handle, self.N, api._ptr(self.means), api._ptr(self.log_scales),
+                                                    api._ptr(self.quats), api._ptr(self.sh), api._ptr(opac), len(pres),
+                                                    arr), "gs_preprocess_batch_records")
+            return pres
+        pres = [self._alloc_pre(cam) for cam in cams]
         arr = (GsViewPreprocess * max(len(pres), 1))()
         for k, p in enumerate(pres):
             arr[k].cam = ctypes.pointer(p["cam"])
@@ -125,7 +148,6 @@ class SplatPipeline:
                 setattr(arr[k], name, p[key].data_ptr())
         check(c.lib.gs_preprocess_batch(c.handle, self.N, api._ptr(self.means), api._ptr(self.log_scales),
                                         api._ptr(self.quats), api._ptr(self.sh), len(pres), arr), "gs_preprocess_batch")
-        opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity   # once for the batch
         for p in pres:
             p["opac"] = opac
         return pres
@@ -152,6 +174,9 @@ class SplatPipeline:
         if opac is None:
             opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
         tok = dict(c=c, pre=pre, opac=opac, bin=None)
+        # the ctx reads this view's records (or goes back to packing the four arrays)
+        rec = pre.get("rec")
+        check(c.lib.gs_ctx_use_records(c.handle, N if rec is not None else 0, api._ptr(rec)), "gs_ctx_use_records")
         if self.cull_tiles:
             tok["bin"] = api.bin_culled_begin(c, pre["rect"], pre["depths"], self.result_size, self.tile_size,
                                               (pre["centers"], pre["colors"], opac, pre["conics"], self.pixel_offset))
@@ -171,10 +196,12 @@ class SplatPipeline:
                                               want_keys=want_keys)
         image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
                                                       self.pixel_offset)
+        if pre.get("rec") is not None:      # launched: the ctx must not keep reading them on later, unrelated calls
+            check(c.lib.gs_ctx_use_records(c.handle, 0, None), "gs_ctx_use_records")
         if after_blend is not None:
             after_blend()
         state = dict(ctx=c, cam=cam, depths=depths, centers=centers, colors=colors, conics=conics, clamped=clamped,
-                     radii=radii, opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final)
+                     radii=radii, opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final, rec=pre.get("rec"))
         self.stats = dict(D=binning.D)
         return image, state
 
@@ -206,11 +233,16 @@ class SplatPipeline:
         b = state["binning"]
         W, H = self.result_size
         rows = torch.empty((self.N, 16), dtype=torch.float32, device=c.device)
+        rec = state.get("rec")
+        if rec is not None:
+            check(c.lib.gs_ctx_use_records(c.handle, self.N, api._ptr(rec)), "gs_ctx_use_records")
         check(c.lib.gs_blend_backward_rows(
             c.handle, self.N, api._ptr(state["centers"]), api._ptr(state["colors"]), api._ptr(state["opac"]),
             api._ptr(state["conics"]), api._ptr(b.vals), api._ptr(b.ranges), b.D, ctypes.byref(self.bg), W, H,
             self.tile_size, self.pixel_offset, api._ptr(state["n_contrib"]), api._ptr(state["t_final"]),
             api._ptr(dL_dimage.contiguous()), api._ptr(rows)), "gs_blend_backward_rows")
+        if rec is not None:
+            check(c.lib.gs_ctx_use_records(c.handle, 0, None), "gs_ctx_use_records")
         state["rows"] = rows
         return rows
 

@@ -84,6 +84,23 @@ int gs_preprocess_batch(gs_ctx *ctx, int32_t N, const float *means, const float 
                         const float *quats, const float *sh, int32_t n_views,
                         const gs_view_preprocess *views);
 
+/* Record-writing form of gs_preprocess_batch (no counterpart in the reference): instead of centers /
+ * colors / conics each view receives records[N][16] floats, the 64-byte per-gaussian records the
+ * blend and culled-binning kernels read (centre, opacity, alpha threshold, log2-scaled conic, colour),
+ * built from `opacities` (activated, [N]).  gs_ctx_use_records(ctx, N, records) then makes the
+ * culled-binning and blend calls on that ctx take their per-gaussian inputs from `records` and
+ * ignore their centers / colors / opacities / conics arguments (which may be NULL), so no pack pass
+ * runs per view; gs_ctx_use_records(ctx, 0, NULL) returns to the arrays.  The records must stay
+ * unchanged while calls that use them are in flight. */
+typedef struct gs_view_records {
+    const gs_camera *cam;
+    float *records; int32_t *depths; uint8_t *clamped; int32_t *tiles_touched; int32_t *radii;
+} gs_view_records;
+int gs_preprocess_batch_records(gs_ctx *ctx, int32_t N, const float *means, const float *log_scales,
+                                const float *quats, const float *sh, const float *opacities,
+                                int32_t n_views, const gs_view_records *views);
+int gs_ctx_use_records(gs_ctx *ctx, int32_t N, const float *records);
+
 /* Replaces match_gaus_to_tiles (rasterization.py:6-25) + kernel tile_match (setup_gpu.py:23-44)
  * + the per-tile filter and RadixSort (rasterization.py:57,66-71), in O(D) instead of
  * O(tiles*N).  Two phases so the caller owns the D-sized outputs:

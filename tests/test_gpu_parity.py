@@ -536,7 +536,7 @@ def test_preprocess_batch_equals_single_view_calls(gpu_ctx):
         a = 0.05 * (k - 4)
         Rk = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
         views.append(gs.View(cam, Rk, np.array([0.02 * k, -0.01 * k, 0.3 * k])))
-    pres = pipe.preprocess_batch(views)
+    pres = pipe.preprocess_batch(views, records=False)
     for v, pre in zip(views, pres):
         image, st = pipe.forward(v)
         for key in ("centers", "depths", "colors", "conics", "clamped", "radii"):
@@ -810,3 +810,34 @@ def test_blend_adversarial_inputs_vs_oracles(gpu_ctx, seed, tile):
             assert np.abs(g - w).max() <= 0.05 * np.abs(w).max(), (what, np.abs(g - w).max(), np.abs(w).max())
             close = np.abs(g - w) <= 2e-3 * np.abs(w).max()
             assert close.mean() > 0.9, (what, close.mean())
+
+
+def test_record_writing_preprocess_equals_array_path(gpu_ctx):
+    """gs_preprocess_batch_records + gs_ctx_use_records (K1 writes the blend records itself) against
+    gs_preprocess_batch + the per-view pack: identical integer outputs, images, transmittances and lists;
+    gradients to float-atomics noise.  The ctx goes back to the arrays afterwards."""
+    import torch
+    import gsplat_amd as gs
+    cam, R, t, g, rs = synth_scene(40_000, 640, 360, seed=4, fx=400.0)
+    pipe = gs.SplatPipeline(g, rs, ctx=gpu_ctx)
+    views = [gs.View(cam, R, t), gs.View(cam, R, np.array([0.3, -0.2, 0.5]))]
+    pr = pipe.preprocess_batch(views, records=True)
+    pa = pipe.preprocess_batch(views, records=False)
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    for v in range(2):
+        assert pr[v]["centers"] is None and pr[v]["rec"].shape == (pipe.N, 16)
+        for k in ("depths", "rect", "radii", "clamped"):
+            assert torch.equal(pr[v][k], pa[v][k]), k
+        rec = pr[v]["rec"]
+        assert torch.equal(rec[:, 0:2], pa[v]["centers"]) and torch.equal(rec[:, 8:11], pa[v]["colors"])
+        img_r, st_r = pipe.forward(views[v], pre=pr[v])
+        img_a, st_a = pipe.forward(views[v], pre=pa[v])
+        assert torch.equal(img_r, img_a) and torch.equal(st_r["t_final"], st_a["t_final"])
+        assert torch.equal(st_r["binning"].vals, st_a["binning"].vals)
+        dL = torch.randn(rs[0], rs[1], 3, generator=gen).to(img_r.device)
+        rows_r = pipe.backward_rows(st_r, dL)
+        rows_a = pipe.backward_rows(st_a, dL)
+        assert (rows_r - rows_a).abs().max().item() <= 1e-5 * rows_a.abs().max().item()
+    # the ctx is back on the arrays: a plain API call with other inputs is not affected by the records
+    img2, _ = pipe.forward(views[0])
+    assert torch.equal(img2, pipe.forward(views[0], pre=pa[0])[0])
