@@ -238,6 +238,8 @@ def main():
             if N == 1_000_000 and (W, H) == (1920, 1080) and dom in pmc and "hbm_traffic_bytes" in pmc[dom]:
                 roofline["traffic"] = int(pmc[dom]["hbm_traffic_bytes"])
                 roofline["traffic_source"] = "profiles/r01_pmc_summary.json"
+                # avg_launch_ms above is measured while four views share the GPU; the same kernel alone:
+                roofline["single_stream_launch_ms"] = round(pmc[dom]["avg_duration_us_under_pmc"] / 1e3, 4)
         except (OSError, ValueError):
             pass
         if dom in ("blend_forward", "blend_backward"):
