@@ -422,10 +422,10 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
 
-// waves per SIMD the register allocator must leave room for (measured: spilling to reach more
-// resident waves costs more than it gains)
+// waves per SIMD the register allocator must leave room for: 8 (64 VGPRs) spills 60 bytes per lane of
+// the staging code to scratch -- same speed, but 60 MB of HBM writes and 170 MB of re-reads per view
 #ifndef GS_FWD_WAVES
-#define GS_FWD_WAVES 8
+#define GS_FWD_WAVES 7
 #endif
 __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_kernel(QuadArgs a, float *__restrict__ image,
                                                                          int32_t *__restrict__ n_contrib,
