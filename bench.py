@@ -48,9 +48,6 @@ def parse():
                     help="which kernels get HIP events inside the timed region")
     ap.add_argument("--k8-early-lanes", type=int, default=None,
                     help="lanes whose views get an early parameter-backward launch (default: half of them)")
-    ap.add_argument("--k1-first", type=int, default=0, help="views in the first preprocess launch (0: one per lane)")
-    ap.add_argument("--k8-tail", type=int, default=None,
-                    help="views left to the final parameter-backward launch (the rest start early on the main stream; 0: one launch)")
     ap.add_argument("--concurrent-views", type=int, default=4, help="local views in flight on separate streams")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: single-view forward render")
     return ap.parse_args()
@@ -136,7 +133,7 @@ def main():
             image, _ = pipe.forward(views[0])
             return image
         return gs.train_step(pipe, views, targets, grads, concurrent_views=args.concurrent_views,
-                             k8_tail=args.k8_tail, k1_first=args.k1_first, k8_early_lanes=args.k8_early_lanes)
+                             k8_early_lanes=args.k8_early_lanes)
 
     trace = os.environ.get("GS_BENCH_TRACE") == "1"
 

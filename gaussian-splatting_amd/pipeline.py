@@ -306,15 +306,72 @@ class Optimizer:
               "gs_adam_step")
 
 
+def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale):
+    """Forward, loss gradient and K7 of this rank's views on n_lanes concurrent lanes.  Returns
+    (states, done events per view, lanes)."""
+    main = torch.cuda.current_stream(pipe.ctx.device)
+    # a process has 4 hardware queues (GPU_MAX_HW_QUEUES): up to 3 side lanes, the main stream is the 4th
+    if n_lanes > 3:
+        lanes = pipe.lanes(n_lanes - 1) + [(pipe.ctx, main)]
+    else:
+        lanes = pipe.lanes(n_lanes)
+    # K1 for the first view of every lane, then (on the main stream, under those views' binning) for the rest
+    first = min(n_lanes, len(mine))
+    pres = pipe.preprocess_batch([views[v] for v in mine[:first]])
+    for _, stream in lanes:
+        stream.wait_stream(main)
+    pre_ready = None
+    if len(mine) > first:
+        pres += pipe.preprocess_batch([views[v] for v in mine[first:]])
+        pre_ready = main.record_event()
+    # Two workspaces per lane: the tile count of a lane's next view is launched right behind this
+    # view's K6, so its result is on the host long before the lane has finished K7 and the host
+    # never waits for a whole view (a lane's queue does not run dry between views).
+    alts = pipe.alt_contexts(n_lanes)
+    tokens = {}
+
+    def begin(k):
+        if k >= len(mine):
+            return
+        ctx, stream = lanes[k % n_lanes]
+        if (k // n_lanes) & 1:
+            ctx = alts[k % n_lanes]
+        with torch.cuda.stream(stream):
+            if k >= first:
+                stream.wait_event(pre_ready)
+            tokens[k] = pipe.forward_begin(views[mine[k]], ctx=ctx, pre=pres[k])
+
+    for k in range(first):
+        begin(k)
+    states, done = [], []
+    # host order per round of n_lanes views: sort + K6 (+ the lane's next count) for every lane, then
+    # loss + K7 for every lane
+    for r0 in range(0, len(mine), n_lanes):
+        ks = range(r0, min(r0 + n_lanes, len(mine)))
+        fwd = {}
+        for k in ks:
+            with torch.cuda.stream(lanes[k % n_lanes][1]):
+                fwd[k] = pipe.forward_finish(tokens.pop(k), after_blend=lambda k=k: begin(k + n_lanes))
+        for k in ks:
+            stream = lanes[k % n_lanes][1]
+            image, state = fwd[k]
+            with torch.cuda.stream(stream):
+                dL, _ = pipe.image_loss(image, targets[mine[k]], loss_kind, scale, losses[k:k + 1], ctx=state["ctx"])
+                pipe.backward_rows(state, dL)
+                done.append(stream.record_event())
+            states.append(state)
+    return states, done, lanes
+
+
 def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,
-               k8_tail=None, k1_first=None, k8_early_lanes=None):
+               k8_early_lanes=None):
     """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
     formed together with dL/dimage by the fused native kernel.  concurrent_views > 1 renders that
-    many local views at a time on separate streams (the 4th is the main stream); with fewer, the
-    parameter backward of all but the last k8_tail views starts early on the idle main stream
-    (0: one launch at the end; None: 1 when the main stream renders no view).  Returns (sum of local losses as a
+    many local views at a time on separate streams (the 4th is the main stream).  The views of the
+    first k8_early_lanes lanes (default: half of them) get their parameter backward as soon as they are
+    complete, under the blend kernels of the lanes still running.  Returns (sum of local losses as a
     device scalar, number of local views)."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -325,8 +382,7 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     scale = 1.0 if loss_scale is None else loss_scale
     states = []
     n_lanes = min(int(concurrent_views), len(mine)) if hasattr(pipe, "lanes") else 1
-    native_loss = hasattr(pipe, "image_loss")
-    if not native_loss:        # duck-typed stand-ins (CPU tests): plain torch MSE
+    if not hasattr(pipe, "image_loss"):        # duck-typed stand-ins (CPU tests): plain torch MSE
         loss = torch.zeros((), dtype=torch.float32, device=pipe.ctx.device)
         gscale = scale * 2.0 / (W * H * 3)
         for v in mine:
@@ -340,93 +396,22 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
             dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
         return loss, len(mine)
     losses = torch.zeros(max(len(mine), 1), dtype=torch.float32, device=pipe.ctx.device)
-    early = 0
+    late = None
     if n_lanes > 1:
-        # independent views alternate between lanes (stream + workspace each); a lane's host sync
-        # (the duplicate count D) only waits for that lane.  The HBM-bound K1 of the later views and
-        # the latency-bound K8 of the earlier ones run on the main stream under the VALU-bound blend
-        # kernels of the other views.
         main = torch.cuda.current_stream(pipe.ctx.device)
-        # a process has 4 hardware queues: up to 3 side lanes, and the main stream is the 4th lane
-        lanes = pipe.lanes(min(n_lanes, 3))
-        main_is_lane = n_lanes > 3
-        if main_is_lane:
-            lanes = pipe.lanes(n_lanes - 1) + [(pipe.ctx, main)]
-        if k8_tail is None:
-            k8_tail = 0 if main_is_lane else 1
-        first = min(k1_first or n_lanes, len(mine))
-        early = len(mine) - k8_tail if (k8_tail and len(mine) - k8_tail >= 2) else 0
-        pres = pipe.preprocess_batch([views[v] for v in mine[:first]])
-        for _, stream in lanes:
-            stream.wait_stream(main)
-        pre_ready = None
-        if len(mine) > first:
-            pres += pipe.preprocess_batch([views[v] for v in mine[first:]])
-            pre_ready = main.record_event()
-        # two workspaces per lane: the count of a lane's next view is launched right behind this view's
-        # K6, so its result is on the host long before the lane has finished K7 and the host never
-        # waits for a whole view (a lane's queue does not run dry between views)
-        alts = pipe.alt_contexts(n_lanes)
-        tokens = {}
-
-        def begin(k):
-            if k >= len(mine):
-                return
-            ctx, stream = lanes[k % n_lanes]
-            if (k // n_lanes) & 1:
-                ctx = alts[k % n_lanes]
-            with torch.cuda.stream(stream):
-                if k >= first:
-                    stream.wait_event(pre_ready)
-                tokens[k] = pipe.forward_begin(views[mine[k]], ctx=ctx, pre=pres[k])
-
-        for k in range(min(n_lanes, len(mine))):
-            begin(k)
-        done = []
-        # Host order per round of n_lanes views: sort + K6 (+ the lane's next count) for every lane
-        # first, then loss + K7 for every lane -- the host is the slower side while the lanes fill up
-        # at the start of a step, and this puts a K6 on every lane in half the time.
-        for r0 in range(0, len(mine), n_lanes):
-            ks = range(r0, min(r0 + n_lanes, len(mine)))
-            fwd = {}
-            for k in ks:
-                _, stream = lanes[k % n_lanes]
-                with torch.cuda.stream(stream):
-                    fwd[k] = pipe.forward_finish(tokens.pop(k), after_blend=lambda k=k: begin(k + n_lanes))
-            for k in ks:
-                _, stream = lanes[k % n_lanes]
-                image, state = fwd[k]
-                with torch.cuda.stream(stream):
-                    dL, _ = pipe.image_loss(image, targets[mine[k]], loss_kind, scale, losses[k:k + 1], ctx=state["ctx"])
-                    pipe.backward_rows(state, dL)
-                    done.append(stream.record_event())
-                states.append(state)
-                if k + 1 == early and states_hook is None:
-                    for e in done:
-                        main.wait_event(e)
-                    pipe.backward_params(states[:early], grads, accumulate=False)
-        if states_hook is not None:
-            early = 0
-        # The lanes do not finish together (the hardware serves the queues in a fixed order): the
-        # views of the first k8_early_lanes lanes get their K8 on lane 0's stream as soon as they are
-        # complete, under the blend kernels of the lanes still running; the rest follow after the join.
+        states, done, lanes = _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale)
+        # The lanes do not finish together (the hardware serves the queues in a fixed order): K8 of the
+        # early lanes' views runs on lane 0's stream while the others still blend.
         if k8_early_lanes is None:
-            k8_early_lanes = n_lanes // 2 if main_is_lane else 0
-        early_set = [k for k in range(len(mine)) if k % n_lanes < k8_early_lanes]
-        if early == 0 and states_hook is None and 2 <= len(early_set) < len(mine):
+            k8_early_lanes = n_lanes // 2 if n_lanes > 3 else 0
+        early = [k for k in range(len(mine)) if k % n_lanes < k8_early_lanes]
+        if states_hook is None and 2 <= len(early) < len(mine):
             ctx0, stream0 = lanes[0]
             with torch.cuda.stream(stream0):
-                for k in early_set:
+                for k in early:
                     stream0.wait_event(done[k])
-                pipe.backward_params([states[k] for k in early_set], grads, accumulate=False, ctx=ctx0)
-            late = [st for k, st in enumerate(states) if k not in set(early_set)]
-            for _, stream in lanes:
-                main.wait_stream(stream)
-            loss = losses.sum()
-            pipe.backward_params(late, grads, accumulate=True)
-            if distributed and world > 1:
-                dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
-            return loss, len(mine)
+                pipe.backward_params([states[k] for k in early], grads, accumulate=False, ctx=ctx0)
+            late = [st for k, st in enumerate(states) if k not in set(early)]
         for _, stream in lanes:
             main.wait_stream(stream)
     else:
@@ -439,8 +424,11 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     loss = losses.sum()
     if states_hook is not None:      # e.g. Densifier.accumulate: per-view blend gradients are still alive here
         states_hook(states)
-    # one pass over the gaussians for all local views; writes (not adds) every gradient
-    pipe.backward_params(states[early:], grads, accumulate=early > 0)
+    # one pass over the gaussians for the (remaining) local views; writes, or adds to the early launch
+    if late is None:
+        pipe.backward_params(states, grads, accumulate=False)
+    else:
+        pipe.backward_params(late, grads, accumulate=True)
     if distributed and world > 1:
         dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
     return loss, len(mine)
