@@ -417,9 +417,12 @@ __global__ __launch_bounds__(RADIX_THREADS) void radix_scan_kernel(uint32_t nblo
 
 // vals_in == nullptr: the value of key i is i (first pass of the depth sort).
 // keys_out == nullptr: only the values are wanted (last pass of the depth sort).
+// NBITS (digit width) is a template parameter: the ballot matching below is the kernel's cost (it is bound
+// by instruction issue, not by HBM), and a runtime width puts a branch around every one of its steps.
+template <int NBITS>
 __global__ __launch_bounds__(RADIX_THREADS) void radix_scatter_kernel(
     uint32_t n, const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift, uint32_t mask, int nbits,
+    uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift, uint32_t mask,
     uint32_t nblocks, const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals) {
     __shared__ uint32_t s_cnt[RADIX_WAVES][RADIX_BINS];   // per-wave digit counts -> exclusive wave bases
     __shared__ uint32_t s_lbase[RADIX_BINS];              // where digit d starts inside this block
@@ -449,24 +452,33 @@ __global__ __launch_bounds__(RADIX_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
 
-    volatile uint32_t *cnt = &s_cnt[w][0];
+    // plain LDS accesses: a volatile pointer here decays to a generic one and every counter access becomes a
+    // flat load / store with a full wait.  LDS operations of one wave execute in order; the fences keep the
+    // compiler from moving them across each other.
+    uint32_t *cnt = &s_cnt[w][0];
 #pragma unroll
     for (int k = 0; k < RADIX_ITEMS; k++) {
         const bool valid = wbase + k * 64 + lane < n;
         const uint32_t d = (key[k] >> shift) & mask;
-        unsigned long long peers = __ballot(valid);   // lanes of this wave holding the same digit
+        // lanes of this wave holding the same digit: per bit, keep the lanes whose bit equals mine.
+        // ~(ballot ^ m) with m = all ones where my bit is set: one xnor + one and per half and bit.
+        const unsigned long long vb = __ballot(valid);
+        uint32_t peers_lo = (uint32_t)vb, peers_hi = (uint32_t)(vb >> 32);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            if (b < nbits) {
-                const bool bit = (d >> b) & 1u;
-                const unsigned long long bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-            }
+        for (int b = 0; b < NBITS; b++) {
+            const uint32_t bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit != 0u);
+            const uint32_t m = 0u - bit;
+            peers_lo &= ~((uint32_t)bal ^ m);
+            peers_hi &= ~((uint32_t)(bal >> 32) ^ m);
         }
-        const uint32_t r = __popcll(peers & lt);
+        const unsigned long long peers = ((unsigned long long)peers_hi << 32) | peers_lo;
+        const uint32_t r = __popc(peers_lo & (uint32_t)lt) + __popc(peers_hi & (uint32_t)(lt >> 32));
         const uint32_t prev = cnt[d];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (valid && r == 0) cnt[d] = prev + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         rank[k] = prev + r;     // position among this wave's keys of digit d
     }
@@ -560,9 +572,17 @@ int radix_pass(gs_ctx *ctx, uint32_t n, const uint32_t *keys_in, const int32_t *
                        mask, nblocks, table);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, nblocks, table,
                        totals);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(RADIX_THREADS), 0, ctx->stream, n, keys_in, vals_in,
-                       keys_out, vals_out, shift, mask, nbits, nblocks, (const uint32_t *)table,
-                       (const uint32_t *)totals);
+#define GS_SCATTER(NB)                                                                                          \
+    case NB:                                                                                                    \
+        hipLaunchKernelGGL(radix_scatter_kernel<NB>, dim3(nblocks), dim3(RADIX_THREADS), 0, ctx->stream, n, keys_in, \
+                           vals_in, keys_out, vals_out, shift, mask, nblocks, (const uint32_t *)table,          \
+                           (const uint32_t *)totals);                                                           \
+        break;
+    switch (nbits) {
+        GS_SCATTER(1) GS_SCATTER(2) GS_SCATTER(3) GS_SCATTER(4) GS_SCATTER(5) GS_SCATTER(6) GS_SCATTER(7) GS_SCATTER(8)
+        default: return gs_set_error(GS_ERR_ARG, "radix_pass: %d bits per pass", nbits);
+    }
+#undef GS_SCATTER
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
