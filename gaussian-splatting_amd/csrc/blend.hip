@@ -430,24 +430,23 @@ __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballo
 __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_kernel(QuadArgs a, float *__restrict__ image,
                                                                          int32_t *__restrict__ n_contrib,
                                                                          float *__restrict__ t_final) {
-    __shared__ float4 s_geo_[QUAD_WAVES][64];
-    __shared__ float4 s_con_[QUAD_WAVES][64];   // .w = original list index (bits)
-    __shared__ float4 s_rgb_[QUAD_WAVES][64];
+    // per wave: 64 staged records of 12 words (geo | con | rgb) at a fixed stride, so one address serves the
+    // three reads of an entry; con.w = original list index + 1 (bits)
+    __shared__ float4 s_rec_[QUAD_WAVES][3][64];
     __shared__ unsigned s_qm_[QUAD_WAVES][64];
 
     const int wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * QUAD_WAVES + wv;
     if (tile >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
     GS_STAMP_BEGIN();
-    float4 *s_geo = s_geo_[wv], *s_con = s_con_[wv], *s_rgb = s_rgb_[wv];
+    float4 *s_geo = s_rec_[wv][0], *s_con = s_rec_[wv][1], *s_rgb = s_rec_[wv][2];
     unsigned *s_qm = s_qm_[wv];
     const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
     const int lane = threadIdx.x & 63;
     const int qy = lane & 7, qx = lane >> 3;
     const int X0 = tx * TILE, Y0 = ty * TILE;
     const float off = a.pixel_offset;
-    const float fx0 = (float)(X0 + qx) - off, fx1 = fx0 + 8.0f;
-    const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
+    const float fx0 = (float)(X0 + qx) - off, fy0 = (float)(Y0 + qy) - off;
     const float xlo = (float)X0 - off, ylo = (float)Y0 - off;
     const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
     const int len = rg.y - rg.x;
@@ -489,7 +488,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
         const int n = __popcll(m);
         if (qm != 0u) {
             const int pos = __popcll(m & ((1ull << lane) - 1ull));
-            con.w = __int_as_float(i);
+            con.w = __int_as_float(i + 1);
             s_geo[pos] = geo;
             s_con[pos] = con;
             s_rgb[pos] = a.rec[(size_t)g * 4 + 2];
@@ -507,10 +506,12 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
             const float4 ge = s_geo[j];
             const float4 co = s_con[j];
             const float4 rgb = s_rgb[j];
+            const float dx0 = ge.x - fx0, dy0 = ge.y - fy0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (!((live[k] >> j) & 1ull)) continue;     // scalar test
-                const float dx = ge.x - ((k >> 1) ? fx1 : fx0), dy = ge.y - ((k & 1) ? fy1 : fy0);
+                // the far quadrants are 8 pixels on: one subtraction from the near offset (identically in K6 and K7)
+                const float dx = (k >> 1) ? dx0 - 8.0f : dx0, dy = (k & 1) ? dy0 - 8.0f : dy0;
                 const float adx = co.x * dx, cdy = co.z * dy;
                 const float p = __builtin_fmaf(dx, __builtin_fmaf(co.y, dy, adx), cdy * dy);
                 const float G = __builtin_amdgcn_exp2f(p);
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
                     Tfin[k] = brk ? T[k] : Tfin[k];
                     tT = brk ? 0.0f : tT;
                     thr[k] = brk ? 0.0f : thr[k];
-                    last[k] = brk ? __float_as_int(co.w) + 1 : last[k];
+                    last[k] = brk ? __float_as_int(co.w) : last[k];
                 }
                 C[k][0] = __builtin_fmaf(rgb.x, w, C[k][0]);
                 C[k][1] = __builtin_fmaf(rgb.y, w, C[k][1]);
@@ -584,8 +585,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     const int qy = lane & 7, qx = lane >> 3;
     const int X0 = tx * TILE, Y0 = ty * TILE;
     const float off = a.pixel_offset;
-    const float fx0 = (float)(X0 + qx) - off, fx1 = fx0 + 8.0f;
-    const float fy0 = (float)(Y0 + qy) - off, fy1 = fy0 + 8.0f;
+    const float fx0 = (float)(X0 + qx) - off, fy0 = (float)(Y0 + qy) - off;
     const float xlo = (float)X0 - off, ylo = (float)Y0 - off;
     const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
 
@@ -671,13 +671,15 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
             const float4 rgb = s_rgb[j];
             float s_x = 0.f, s_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f, g_q = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
             bool any_valid = false;
+            const float dx0 = ge.x - fx0, dy0 = ge.y - fy0;
 #ifdef GS_STAMPS
             int n_valid_px = 0;
 #endif
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (!((live[k] >> j) & 1ull)) continue;     // scalar test
-                const float dx = ge.x - ((k >> 1) ? fx1 : fx0), dy = ge.y - ((k & 1) ? fy1 : fy0);
+                // the far quadrants are 8 pixels on: one subtraction from the near offset (identically in K6 and K7)
+                const float dx = (k >> 1) ? dx0 - 8.0f : dx0, dy = (k & 1) ? dy0 - 8.0f : dy0;
                 const float adx = co.x * dx, cdy = co.z * dy;
                 const float p = __builtin_fmaf(dx, __builtin_fmaf(co.y, dy, adx), cdy * dy);
                 const float G = __builtin_amdgcn_exp2f(p);
