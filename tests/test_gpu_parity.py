@@ -841,3 +841,44 @@ def test_record_writing_preprocess_equals_array_path(gpu_ctx):
     # the ctx is back on the arrays: a plain API call with other inputs is not affected by the records
     img2, _ = pipe.forward(views[0])
     assert torch.equal(img2, pipe.forward(views[0], pre=pa[0])[0])
+
+
+def test_extreme_parameters_stay_finite_and_match_autograd(gpu_ctx):
+    """Parameters at the edges of what the path accepts -- needle and pancake scales, un-normalised
+    quaternions (norm 1e-3 .. 1e3), gaussians behind / on the near plane / far outside the frustum,
+    opacities at 0, 1e-3, .99 and 1, strongly negative SH (clamped colours) -- through K1 -> culled
+    binning -> K6 -> K7 -> K8: everything finite, parameter gradients within a loose bar of fp64
+    autograd (the branch flips such inputs provoke move single pixels)."""
+    import torch
+    import gsplat_amd as gs
+    W, H = 160, 112
+    cam, R, t, g, rs = synth_scene(600, W, H, seed=17, fx=120.0, log_scale=(1.0, 3.0))
+    rng = np.random.default_rng(18)
+    n = len(g.center)
+    g.scaling[:100] = rng.uniform(-6.0, 6.0, (100, 3)).astype(np.float32)              # needles, pancakes, dots, blobs
+    g.rotation[100:200] *= np.float32(10.0) ** rng.uniform(-3, 3, (100, 1)).astype(np.float32)
+    g.center[200:230, 2] = rng.uniform(-5.0, 0.05, 30).astype(np.float32)             # behind / before the near plane
+    g.center[230:240, 2] = np.float32(0.2)                                            # at the near plane (forward_pass.py:66)
+    g.center[240:270, 0] *= np.float32(50.0)                                          # far outside the frustum
+    g.opacity[270:300] = rng.choice(np.float32([0.0, 1e-3, 1 / 255, 0.99, 1.0]), 30)
+    g.spherical_harmonics[300:360] -= np.float32(2.0)                                 # clamped colours
+    d = as_record(cam, R, t, g, rs, bg=(.3, .2, .1))
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, background=(.3, .2, .1), ctx=gpu_ctx)
+    view = gs.View(cam, R, t)
+    image, st = pipe.forward(view)
+    assert bool(torch.isfinite(image).all()) and bool(torch.isfinite(st["t_final"]).all())
+    wimg = rng.normal(size=(W, H, 3)).astype(np.float32)
+    grads = gs.FlatGrads(pipe.N, image.device)
+    pipe.backward(st, torch.tensor(wimg, device=image.device), grads, accumulate=False)
+    assert bool(torch.isfinite(grads.flat).all())
+    p, aux = _autograd_reference(d, wimg, 0.5)
+    got = dict(in_center=grads.means, in_scaling=grads.log_scales, in_rotation=grads.quats, in_opacity=grads.opacity,
+               in_sh=grads.sh.reshape(n, 3, 16))
+    for k, gt in got.items():
+        ref = p[k].grad.numpy().reshape(gt.shape)
+        fin = np.isfinite(ref)
+        assert fin.mean() > 0.99, k
+        gv = gt.cpu().numpy().astype(np.float64)
+        scale = np.abs(ref[fin]).max()
+        close = np.abs(gv - ref)[fin] <= 2e-3 * scale
+        assert close.mean() > 0.995 and np.abs(gv - ref)[fin].max() <= 0.05 * scale, (k, close.mean(), np.abs(gv - ref)[fin].max(), scale)
