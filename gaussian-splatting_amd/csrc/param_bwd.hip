@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
         for (int k = 0; k < 3; k++) in.clamp[k] = V.clamped[3 * i + k] != 0;
         return in;
     };
-    Inputs nxt = fetch(0);
+    Inputs nxt = {};
+    if (args.n_views > 0) nxt = fetch(0);      // an empty batch only writes zeros (a rank without views)
 
 #pragma unroll 1
     for (int v = 0; v < args.n_views; v++) {

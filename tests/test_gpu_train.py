@@ -232,3 +232,24 @@ def test_train_model_with_densification(gpu_ctx):
     assert len(hist) == 13 and np.all(np.isfinite(hist))
     assert sum("densify" in m for m in msgs) == 2
     assert 150 < len(out.center) <= 400
+
+
+@pytest.mark.gpu
+def test_parameter_backward_of_an_empty_view_batch_writes_zeros(gpu_ctx):
+    """A rank that received no view of a step still calls the batched K8 before the all-reduce: it must
+    overwrite its gradient buffer with zeros (and not read any per-view array)."""
+    import torch
+    import gsplat_amd as gs
+    from conftest import synth_scene
+    cam, R, t, g, rs = synth_scene(1000, 64, 48, seed=2, fx=60.0)
+    pipe = gs.SplatPipeline(g, rs, ctx=gpu_ctx)
+    grads = gs.FlatGrads(pipe.N, gpu_ctx.device)
+    grads.flat.fill_(3.0)
+    pipe.backward_params([], grads, accumulate=False)
+    torch.cuda.synchronize()
+    for part in (grads.means, grads.log_scales, grads.quats, grads.opacity, grads.sh):
+        assert float(part.abs().max()) == 0.0
+    # train_step with an empty shard does the same
+    grads.flat.fill_(3.0)
+    loss, n = gs.train_step(pipe, [], [], grads)
+    assert n == 0 and float(grads.means.abs().max()) == 0.0
