@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--views-per-rank", type=int, default=8, help="views each rank renders per step (weak scaling)")
     ap.add_argument("--views", type=int, default=0, help="fixed GLOBAL batch instead (strong scaling; needs --views-per-rank 0)")
     ap.add_argument("--log-scale", type=float, nargs=2, default=(1.0, 3.0))
-    ap.add_argument("--cpu-views", type=int, default=24, help="frames rendered by the CPU baseline (about 0.4 s each on 16 threads)")
+    ap.add_argument("--cpu-views", type=int, default=32, help="frames rendered by the CPU baseline (about 0.4 s each on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timing", choices=["dominant", "all", "none"], default="dominant",
                     help="which kernels get HIP events inside the timed region")
