@@ -603,6 +603,7 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
                     int32_t res_h, int32_t tile_size, const float4 *rec, float pixel_offset) {
     int rc;
     ctx->bin_culled = rec != nullptr;
+    ctx->packed_fresh = false;    // only a gs_blend_forward that directly follows gs_bin_fill_culled may reuse the records
     ctx->bin_N = -1;
     ctx->bin_D = -1;
     ctx->bin_max_depth = 0;
@@ -672,6 +673,7 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
              int32_t *vals, int32_t *ranges) {
     int rc;
     GS_REQUIRE(ranges, "gs_bin_fill: ranges is NULL");
+    ctx->packed_fresh = false;
     if (ctx->bin_N != N || ctx->bin_D != D || ctx->bin_culled != (rec != nullptr))
         return gs_set_error(GS_ERR_STATE, "gs_bin_fill: call gs_bin_count first with the same inputs "
                             "(have N=%d D=%lld, got N=%d D=%lld)", ctx->bin_N, (long long)ctx->bin_D, N,

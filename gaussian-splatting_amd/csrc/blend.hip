@@ -865,7 +865,11 @@ extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, co
     GS_REQUIRE(image && n_contrib && t_final, "gs_blend_forward: NULL output");
     GS_HIP(hipSetDevice(ctx->device));
     const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
-    switch (ctx->ppt) {
+    // only the quad kernels read caller-owned records (gs_ctx_use_records): with records the per-array
+    // arguments may be NULL, so the 1- and 2-pixel kernels must not be chosen
+    const int ppt = ctx->ext_records ? 4 : ctx->ppt;
+    if (ppt != 4) ctx->packed_fresh = false;      // the array kernels consume nothing that was packed
+    switch (ppt) {
         case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_FWD); hipLaunchKernelGGL(blend_fwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, image, n_contrib, t_final); } break;
         case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_FWD); hipLaunchKernelGGL(blend_fwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, image, n_contrib, t_final); } break;
         default: {
@@ -887,7 +891,7 @@ int blend_backward_into_rows(gs_ctx *ctx, const BlendArgs &a, int32_t N, int64_t
     int rc;
     GS_HIP(hipMemsetAsync(rows, 0, (size_t)N * GRAD_ROW * sizeof(float), ctx->stream));
     if (D <= 0) return GS_OK;
-    switch (ctx->ppt) {
+    switch (ctx->ext_records ? 4 : ctx->ppt) {    // records are read by the quad kernel only (see gs_blend_forward)
         case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
         case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
         default: {

@@ -136,6 +136,7 @@ extern "C" int gs_ctx_use_records(gs_ctx *ctx, int32_t N, const float *records) 
     GS_REQUIRE(ctx, "gs_ctx_use_records: ctx is NULL");
     GS_REQUIRE(((uintptr_t)records & 15) == 0, "gs_ctx_use_records: records must be 16-byte aligned");
     GS_REQUIRE(records == nullptr || N >= 0, "gs_ctx_use_records: N=%d < 0", N);
+    ctx->packed_fresh = false;
     ctx->ext_records = reinterpret_cast<const float4 *>(records);
     ctx->ext_records_N = records ? N : -1;
     return GS_OK;

@@ -59,17 +59,22 @@ class Densifier:
         avg = self.grad_accum / self.denom.clamp(min=1.0)
         hot = avg >= self.grad_threshold
         big = self._activated_scales().max(dim=1).values > self.percent_dense * self.scene_extent
-        clone_mask = hot & ~big
-        split_mask = hot & big
+        # Kerbl et al. section 5.2 prune after clone / split, new points included: a clone has its parent's
+        # opacity and a split's children too, so a prunable gaussian spawns nothing (and is dropped below)
+        opac = torch.sigmoid(p.opacity) if p.opacity_is_logit else p.opacity
+        prunable = opac < self.min_opacity
+        clone_mask = hot & ~big & ~prunable
+        split_mask = hot & big & ~prunable
         if self.max_gaussians is not None:
-            room = max(0, int(self.max_gaussians) - p.N)
+            # a clone adds one gaussian and a split a net one (two children replace the parent); the budget
+            # is what is left AFTER pruning
+            room = max(0, int(self.max_gaussians) - (p.N - int(prunable.sum().item())))
             for m in (split_mask, clone_mask):          # keep the first `room` candidates (deterministic)
                 idx = torch.nonzero(m).flatten()
                 if idx.numel() > room:
                     m[idx[room:]] = False
                 room -= int(m.sum().item())
                 room = max(room, 0)
-        opac = torch.sigmoid(p.opacity) if p.opacity_is_logit else p.opacity
         groups = [p.means, p.log_scales, p.quats, p.opacity, p.sh]
 
         def take(mask):
@@ -91,7 +96,7 @@ class Densifier:
                 eps = torch.randn(n_split, 3, generator=self.gen, device=sm.device, dtype=torch.float32)
                 offs = torch.bmm(R, (eps * std).unsqueeze(-1)).squeeze(-1)
                 children.append([sm + offs, ss - torch.log(torch.tensor(self.split_factor, device=sm.device)), sq, so, ssh])
-        keep = ~split_mask & ~(opac < self.min_opacity)
+        keep = ~split_mask & ~prunable
         kept = take(keep)
         parts = [kept, clones] + children
         new_groups = [torch.cat([part[k] for part in parts], dim=0).contiguous() for k in range(5)]

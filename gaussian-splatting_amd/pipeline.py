@@ -51,6 +51,23 @@ class FlatGrads:
         self.flat.zero_()
 
 
+class _records:
+    """Binds caller-owned blend records to a ctx for the calls inside the block (gs_ctx_use_records) and
+    unbinds them on the way out, also when one of those calls raises."""
+
+    def __init__(self, c, N, rec):
+        self.c, self.N, self.rec = c, N, rec
+
+    def __enter__(self):
+        check(self.c.lib.gs_ctx_use_records(self.c.handle, self.N if self.rec is not None else 0, api._ptr(self.rec)),
+              "gs_ctx_use_records")
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.c.lib.gs_ctx_use_records(self.c.handle, 0, None)
+        return False
+
+
 class View:
     def __init__(self, camera, camera_r, camera_t):
         self.camera, self.camera_r, self.camera_t = camera, camera_r, camera_t
@@ -174,12 +191,12 @@ class SplatPipeline:
         if opac is None:
             opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity
         tok = dict(c=c, pre=pre, opac=opac, bin=None)
-        # the ctx reads this view's records (or goes back to packing the four arrays)
-        rec = pre.get("rec")
-        check(c.lib.gs_ctx_use_records(c.handle, N if rec is not None else 0, api._ptr(rec)), "gs_ctx_use_records")
         if self.cull_tiles:
-            tok["bin"] = api.bin_culled_begin(c, pre["rect"], pre["depths"], self.result_size, self.tile_size,
-                                              (pre["centers"], pre["colors"], opac, pre["conics"], self.pixel_offset))
+            # the ctx reads this view's records (or packs the four arrays) while the count is enqueued
+            with _records(c, N, pre.get("rec")):
+                tok["bin"] = api.bin_culled_begin(c, pre["rect"], pre["depths"], self.result_size, self.tile_size,
+                                                  (pre["centers"], pre["colors"], opac, pre["conics"],
+                                                   self.pixel_offset))
         return tok
 
     def forward_finish(self, tok, want_keys=False, after_blend=None):
@@ -189,15 +206,16 @@ class SplatPipeline:
         c.sync_stream()
         cam, centers, depths, colors, conics = pre["cam"], pre["centers"], pre["depths"], pre["colors"], pre["conics"]
         clamped, rect, radii = pre["clamped"], pre["rect"], pre["radii"]
-        if tok["bin"] is not None:
-            binning = api.bin_culled_finish(tok["bin"], want_keys=want_keys)
-        else:
-            binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size, self.tile_size,
-                                              want_keys=want_keys)
-        image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
-                                                      self.pixel_offset)
-        if pre.get("rec") is not None:      # launched: the ctx must not keep reading them on later, unrelated calls
-            check(c.lib.gs_ctx_use_records(c.handle, 0, None), "gs_ctx_use_records")
+        # the records are a per-call binding: whatever raises in between (D >= 2^31, out of memory), the ctx
+        # does not keep a pointer to tensors this call owns
+        with _records(c, self.N, pre.get("rec")):
+            if tok["bin"] is not None:
+                binning = api.bin_culled_finish(tok["bin"], want_keys=want_keys)
+            else:
+                binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size,
+                                                  self.tile_size, want_keys=want_keys)
+            image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
+                                                          self.pixel_offset)
         if after_blend is not None:
             after_blend()
         state = dict(ctx=c, cam=cam, depths=depths, centers=centers, colors=colors, conics=conics, clamped=clamped,
@@ -233,16 +251,12 @@ class SplatPipeline:
         b = state["binning"]
         W, H = self.result_size
         rows = torch.empty((self.N, 16), dtype=torch.float32, device=c.device)
-        rec = state.get("rec")
-        if rec is not None:
-            check(c.lib.gs_ctx_use_records(c.handle, self.N, api._ptr(rec)), "gs_ctx_use_records")
-        check(c.lib.gs_blend_backward_rows(
-            c.handle, self.N, api._ptr(state["centers"]), api._ptr(state["colors"]), api._ptr(state["opac"]),
-            api._ptr(state["conics"]), api._ptr(b.vals), api._ptr(b.ranges), b.D, ctypes.byref(self.bg), W, H,
-            self.tile_size, self.pixel_offset, api._ptr(state["n_contrib"]), api._ptr(state["t_final"]),
-            api._ptr(dL_dimage.contiguous()), api._ptr(rows)), "gs_blend_backward_rows")
-        if rec is not None:
-            check(c.lib.gs_ctx_use_records(c.handle, 0, None), "gs_ctx_use_records")
+        with _records(c, self.N, state.get("rec")):
+            check(c.lib.gs_blend_backward_rows(
+                c.handle, self.N, api._ptr(state["centers"]), api._ptr(state["colors"]), api._ptr(state["opac"]),
+                api._ptr(state["conics"]), api._ptr(b.vals), api._ptr(b.ranges), b.D, ctypes.byref(self.bg), W, H,
+                self.tile_size, self.pixel_offset, api._ptr(state["n_contrib"]), api._ptr(state["t_final"]),
+                api._ptr(dL_dimage.contiguous()), api._ptr(rows)), "gs_blend_backward_rows")
         state["rows"] = rows
         return rows
 

@@ -46,6 +46,14 @@ def train_model(cameras, images, point_cloud_data, learning_rates, ctx=None, que
     counterpart) every k iterations between densify_from and densify_until.  Returns (gaussians,
     history of per-iteration mean losses)."""
     t0 = time.perf_counter() if t0 is None else t0
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if distributed:
+        # every rank must draw the same subset and the same views per iteration ("view v goes to rank
+        # v % world" shards ONE list): rank 0's seed is the seed, whatever the others were given
+        box = [random.SystemRandom().randrange(2 ** 31) if seed is None else int(seed)]
+        dist.broadcast_object_list(box, src=0)
+        seed = box[0]
     rnd = random.Random(seed)
     if gaussians is None:
         gaussians = gio.gaussians_from_point_cloud(point_cloud_data)            # train.py:13
@@ -82,7 +90,15 @@ def train_model(cameras, images, point_cloud_data, learning_rates, ctx=None, que
         loss_sum, n_local = train_step(pipe, views, targets, grads, loss_scale=1.0 / views_per_step,
                                        concurrent_views=concurrent_views, loss_kind=loss,
                                        states_hook=den.accumulate if den else None)
-        mean_loss = float(loss_sum.item()) / max(n_local, 1)
+        if distributed:
+            # the replicated parameters stay in lock-step only if every rank applies the same update:
+            # method="reference" scales it by the loss, so the loss is the mean over the WHOLE batch
+            both = torch.stack([loss_sum.reshape(()).to(torch.float32),
+                                torch.tensor(float(n_local), dtype=torch.float32, device=loss_sum.device)])
+            dist.all_reduce(both, op=dist.ReduceOp.SUM)
+            mean_loss = float(both[0].item()) / max(float(both[1].item()), 1.0)
+        else:
+            mean_loss = float(loss_sum.item()) / max(n_local, 1)
         opt.step(grads, loss=mean_loss)                                           # train.py:51-56
         history.append(mean_loss)
         if den and densify_from <= i <= densify_until and i > 0 and i % densify_every == 0:

@@ -127,7 +127,10 @@ int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int3
  * produced from, so forward and backward must use the same one), while D -- what is sorted, written
  * and staged -- is about halved.  centers / colors / opacities / conics are the arrays the blend
  * calls will be given (they are packed into the ctx's blend records here; a gs_blend_forward that
- * directly follows gs_bin_fill_culled on this ctx with the same arrays reuses them). */
+ * directly follows gs_bin_fill_culled on this ctx with the same arrays reuses them; any other call on
+ * the ctx in between ends that reuse.  The cache is keyed on the four pointers and N only: the arrays'
+ * CONTENTS must be unchanged between gs_bin_count_culled, gs_bin_fill_culled and that gs_blend_forward,
+ * and between a gs_blend_forward and the gs_blend_backward* that consumes its n_contrib / t_final). */
 int gs_bin_count_culled(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
                         const float *centers, const float *colors, const float *opacities,
                         const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,

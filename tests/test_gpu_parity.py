@@ -309,6 +309,38 @@ def test_pipeline_matches_stage_api_and_is_linear(gpu_ctx):
     assert (ga.flat - want).abs().max().item() <= 2e-5 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("ppt", [1, 2])
+def test_pipeline_with_records_under_pixels_per_thread_knob(gpu_ctx, ppt):
+    """SplatPipeline gives the blend calls caller-owned records and NULL per-gaussian arrays; only the
+    one-wave-per-tile kernels read records, so the pixels_per_thread knob must not route these calls to
+    the array kernels (that was a NULL dereference on the GPU)."""
+    import torch
+    import gsplat_amd as gs
+    d = as_record(*dense_scene(), bg=(.2, .1, .3))
+    cam, R, t, g, rs, bg = scene_inputs(d)
+    pipe = gs.SplatPipeline(g, rs, background=bg, opacity_is_logit=False, ctx=gpu_ctx)
+    assert pipe.cull_tiles
+    view = gs.View(cam, R, t)
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    dL = torch.randn(rs[0], rs[1], 3, generator=gen).to(gpu_ctx.device)
+    image4, st4 = pipe.forward(view, pre=pipe.preprocess_batch([view])[0])
+    g4 = gs.FlatGrads(pipe.N, gpu_ctx.device)
+    pipe.backward(st4, dL, g4, accumulate=False)
+    gpu_ctx.set_option("pixels_per_thread", ppt)
+    try:
+        pre = pipe.preprocess_batch([view])[0]
+        assert pre["centers"] is None and pre["rec"] is not None
+        image, st = pipe.forward(view, pre=pre)
+        gk = gs.FlatGrads(pipe.N, gpu_ctx.device)
+        pipe.backward(st, dL, gk, accumulate=False)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_option("pixels_per_thread", 4)
+    assert torch.equal(image, image4)
+    scale = g4.flat.abs().max().item()
+    assert scale > 0 and (gk.flat - g4.flat).abs().max().item() <= 2e-5 * scale
+
+
 def test_full_size_properties(gpu_ctx):
     """BASELINE.json config 2 (1M gaussians, 1920x1080) through size-independent properties, plus
     the full image against the C oracle run on the host cores."""

@@ -175,14 +175,15 @@ def test_densify_clone_split_prune(gpu_ctx):
         m_before = opt.m.clone()
         n_before = pipe.N
         ls_before = pipe.log_scales.cpu().numpy().copy()
+        low = pipe.opacity.cpu().numpy() < 0.005          # as the densifier sees them (after the Adam step)
         stats = den.step()
-        return pipe, opt, stats, vis, big, m_before, n_before, ls_before
+        return pipe, opt, stats, vis, big, m_before, n_before, ls_before, low
 
-    pipe, opt, stats, vis, big, m_before, n_before, ls_before = run(3)
+    pipe, opt, stats, vis, big, m_before, n_before, ls_before, low = run(3)
     # threshold 0 => every gaussian is "hot" (avg >= 0): split the big ones, clone the small ones
-    assert stats["split"] == int(big.sum()) and stats["cloned"] == int((~big).sum())
-    low = np.asarray(g.opacity) < 0.005
-    assert stats["pruned"] == int((low & ~big).sum())
+    # -- except the nearly transparent ones, which spawn nothing and are pruned (3DGS prunes after densifying)
+    assert stats["split"] == int((big & ~low).sum()) and stats["cloned"] == int((~big & ~low).sum())
+    assert stats["pruned"] == int(low.sum()) >= 40
     n_keep = int((~big & ~low).sum())
     assert stats["N"] == pipe.N == n_keep + stats["cloned"] + 2 * stats["split"]
     assert pipe.means.shape == (pipe.N, 3) and pipe.sh.shape == (pipe.N, 3, 16) and pipe.opacity.shape == (pipe.N,)
@@ -194,7 +195,7 @@ def test_densify_clone_split_prune(gpu_ctx):
     assert float(opt.m[:3 * pipe.N].view(pipe.N, 3)[n_keep:].abs().max()) == 0.0
     # split children are smaller by the split factor
     kids = pipe.log_scales[n_keep + stats["cloned"]:]
-    np.testing.assert_allclose(kids[:stats["split"]].cpu().numpy(), ls_before[big] - np.float32(np.log(1.6)), rtol=1e-6)
+    np.testing.assert_allclose(kids[:stats["split"]].cpu().numpy(), ls_before[big & ~low] - np.float32(np.log(1.6)), rtol=1e-6)
     # deterministic for a fixed seed, different for another
     # (float atomics make the gradients, hence the Adam-updated parents, differ in the last bits)
     pipe2 = run(3)[0]
