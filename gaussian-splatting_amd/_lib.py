@@ -67,6 +67,8 @@ SIGNATURES = {
                                         _I32, _I32, _I32, _F, _P, _P, _P]),
     "gs_blend_backward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),
                                          _I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_blend_backward_noalloc": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),
+                                                 _I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_backward_params": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, ctypes.POINTER(GsCamera), _P, _P, _P,
                                           _P, _P, _I32, _P, _P, _P, _P]),
     "gs_blend_backward_rows": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),

@@ -950,3 +950,74 @@ extern "C" int gs_blend_backward_rows(gs_ctx *ctx, int32_t N, const float *cente
     const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
     return blend_backward_into_rows(ctx, a, N, D, tiles, n_contrib, t_final, dL_dimage, grad_rows);
 }
+
+// ------------------------------------------------------------------ allocation-free entry point
+// gs_blend_backward for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+// harnesses that forbid hipMalloc).  No counterpart in the reference.  gs_blend_backward keeps two
+// buffers beyond its inputs and outputs in the ctx's grow-only arena: the packed 64-byte blend records
+// and the 64-byte gradient rows K7 accumulates into.  Here both live in ONE file-scope device array
+// (records first, rows behind them) of a fixed size, so the call reserves nothing.  Every GPU holds
+// its own copy of the array at its own address; gs_scratch_setup (called by gs_ctx_create with the
+// device current) asks HIP for that address once per device, and from then on host code only uses that
+// pointer: the array's NAME is a host-side stand-in, not a device address.
+// GS_NOALLOC_MAX_N (include/gsplat.h) gaussians; 2 x 64 bytes each = 8 MiB per GPU
+static __device__ __align__(256) float4 scratch[(size_t)GS_NOALLOC_MAX_N * 8];
+constexpr int GS_MAX_DEVICES = 64;
+static float4 *g_scratch_ptr[GS_MAX_DEVICES];     // per device: address of that GPU's copy of `scratch`
+
+int gs_scratch_setup(int device) {                // the device must be current
+    if (device < 0 || device >= GS_MAX_DEVICES)
+        return gs_set_error(GS_ERR_ARG, "gs_scratch_setup: device %d out of range (max %d)", device, GS_MAX_DEVICES);
+    if (g_scratch_ptr[device]) return GS_OK;
+    void *p = nullptr;
+    GS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return gs_set_error(GS_ERR_HIP, "gs_scratch_setup: hipGetSymbolAddress returned NULL on device %d", device);
+    g_scratch_ptr[device] = static_cast<float4 *>(p);
+    return GS_OK;
+}
+
+extern "C" int gs_blend_backward_noalloc(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                                         const float *opacities, const float *conics, const int32_t *vals,
+                                         const int32_t *ranges, int64_t D, const float *background_host3,
+                                         int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                                         const int32_t *n_contrib, const float *t_final, const float *dL_dimage,
+                                         float *dL_dcenters, float *dL_dconics, float *dL_dopacities,
+                                         float *dL_dcolors) {
+    BlendArgs a;
+    int rc = fill_args(a, ctx, N, centers, colors, opacities, conics, vals, ranges, D, background_host3,
+                       res_w, res_h, tile_size, pixel_offset);
+    if (rc) return rc;
+    GS_REQUIRE(n_contrib && t_final && dL_dimage, "gs_blend_backward_noalloc: NULL forward state / dL_dimage");
+    GS_REQUIRE(N <= GS_NOALLOC_MAX_N, "gs_blend_backward_noalloc: N=%d exceeds the static scratch (%d gaussians); "
+               "use gs_blend_backward", N, GS_NOALLOC_MAX_N);
+    GS_REQUIRE(N == 0 || (centers && colors && opacities && conics),
+               "gs_blend_backward_noalloc: NULL per-gaussian array (caller-owned records are not used here)");
+    GS_REQUIRE(N == 0 || (dL_dcenters && dL_dconics && dL_dopacities && dL_dcolors),
+               "gs_blend_backward_noalloc: NULL output");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(ctx->device >= 0 && ctx->device < GS_MAX_DEVICES && g_scratch_ptr[ctx->device],
+               "gs_blend_backward_noalloc: no scratch address for device %d (gs_ctx_create sets it up)", ctx->device);
+    GS_HIP(hipSetDevice(ctx->device));
+    float4 *rec = g_scratch_ptr[ctx->device];
+    float *rows = reinterpret_cast<float *>(rec + (size_t)GS_NOALLOC_MAX_N * 4);
+    const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
+    // the array keeps the last call's contents: the records are rewritten for [0,N) and nothing past N is
+    // read; the rows must start at zero
+    hipLaunchKernelGGL(pack_kernel, dim3(gs_div_up(N, 64)), dim3(256), 0, ctx->stream, N, a.centers, colors, opacities,
+                       conics, rec);
+    GS_HIP(hipMemsetAsync(rows, 0, (size_t)N * GRAD_ROW * sizeof(float), ctx->stream));
+    if (D > 0) {
+        QuadArgs q;
+        q.rec = rec; q.vals = a.vals; q.ranges = a.ranges;
+        q.bg[0] = a.bg[0]; q.bg[1] = a.bg[1]; q.bg[2] = a.bg[2];
+        q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
+        q.list_tiles_y = a.list_tiles_y; q.shift = a.shift;
+        q.ntiles = tiles;
+        hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0,
+                           ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
+    }
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, (const float *)rows,
+                       dL_dcenters, dL_dconics, dL_dopacities, dL_dcolors);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}

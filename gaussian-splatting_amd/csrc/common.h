@@ -82,6 +82,8 @@ struct gs_ctx {
 };
 
 int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);
+// blend.hip: looks up this device's copy of the static scratch array (gs_blend_backward_noalloc); device must be current
+int gs_scratch_setup(int device);
 
 // brackets the launches issued during its lifetime with two events on the ctx stream
 struct gs_prof_scope {

@@ -38,6 +38,10 @@ extern "C" int gs_ctx_create(int device, void *stream, gs_ctx **out) {
     GS_REQUIRE(device >= 0 && device < count, "gs_ctx_create: device %d out of range (%d devices)",
                device, count);
     GS_HIP(hipSetDevice(device));
+    {   // once per device, with that device current: the address of its copy of the static scratch array
+        const int rc = gs_scratch_setup(device);
+        if (rc) return rc;
+    }
     gs_ctx *c = new gs_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;

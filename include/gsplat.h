@@ -193,6 +193,26 @@ int gs_backward_params(gs_ctx *ctx, int32_t N, const float *means, const float *
                        const float *dL_dconics, const float *dL_dcolors, int32_t accumulate,
                        float *dL_dmeans, float *dL_dlog_scales, float *dL_dquats, float *dL_dsh);
 
+/* gs_blend_backward without any allocation.  NO counterpart in the reference: it exists for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * Same arguments, same results (to float-atomics rounding) as gs_blend_backward, but the two buffers that
+ * call keeps in the ctx's grow-only arena (the packed 64-byte blend records and the 64-byte gradient rows)
+ * live in one static device array of the library: 2 x 64 bytes x GS_NOALLOC_MAX_N = 8 MiB, held by every GPU
+ * the library runs on until the process ends.  N above GS_NOALLOC_MAX_N is rejected (GS_ERR_ARG, "exceeds
+ * the static scratch").  The call issues only kernel launches and one hipMemsetAsync on the ctx's stream:
+ * no hipMalloc / hipFree / event creation, no host synchronisation.  Every call on a GPU shares that GPU's
+ * array, whatever its ctx or stream: calls that overlap on one GPU race -- serialise them (one stream, or
+ * events).  The per-gaussian arrays must be given (records set with gs_ctx_use_records are not used), and
+ * the kernel is always the one-wave-per-tile kernel (the pixels_per_thread option is ignored). */
+#define GS_NOALLOC_MAX_N 65536
+int gs_blend_backward_noalloc(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                              const float *opacities, const float *conics, const int32_t *vals,
+                              const int32_t *ranges, int64_t D, const float *background_host3,
+                              int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                              const int32_t *n_contrib, const float *t_final, const float *dL_dimage,
+                              float *dL_dcenters, float *dL_dconics, float *dL_dopacities,
+                              float *dL_dcolors);
+
 /* Multi-view forms of the two backward entry points.  No counterpart in the reference, which
  * trains one view per iteration (train.py:18-43); they serve SURVEY section 8(e): a rank renders
  * its shard of the view batch, then converts all of its views' blend gradients to parameter
