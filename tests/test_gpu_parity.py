@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 IMG_RTOL, IMG_ATOL = 1e-4, 2e-5
 GRAD_TOL = 1e-4          # normwise: max|g - ref| <= GRAD_TOL * max|ref|
+ADV_TOL = 1e-4           # adversarial / extreme inputs: the same bar, away from fragile pixels
 
 
 def _fwd(ctx, d, training=True):
@@ -113,10 +114,10 @@ def test_binning_large_bit_exact(gpu_ctx):
 
 
 # ------------------------------------------------------------------ K6 blend forward
-def _check_image(img, ref, fragile, what):
+def _check_image(img, ref, fragile, what, max_fragile=5e-3):
     assert img.shape == ref.shape
     frac = fragile.mean()
-    assert frac < 5e-3, f"{what}: {frac:.2%} fragile pixels"
+    assert frac < max_fragile, f"{what}: {frac:.2%} fragile pixels"
     ok = ~fragile.astype(bool)
     err = np.abs(img - ref)[ok]
     tol = IMG_ATOL + IMG_RTOL * np.abs(ref)[ok]
@@ -536,11 +537,22 @@ def test_tile_size_32_render_path(gpu_ctx, name):
     keys, vals, ranges = ref_np.bin_duplicates(o["tiles_touched"], o["depths"], rs, 32)
     assert np.array_equal(b.keys.cpu().numpy().view(np.uint64), keys)
     assert np.array_equal(b.vals.cpu().numpy(), vals) and np.array_equal(b.ranges.cpu().numpy(), ranges)
+    # fragile pixels from the fp64 C oracle: every 16x16 block blends its 32-tile's list
+    tx32, ty32 = ref_np.tile_grid(rs, 32)
+    tx16, ty16 = ref_np.tile_grid(rs, 16)
+    r16 = np.zeros((tx16 * ty16, 2), dtype=np.int32)
+    for i in range(tx16):
+        for j in range(ty16):
+            r16[i * ty16 + j] = ranges[(i // 2) * ty32 + (j // 2)]
+    refc, _, _, fragile, _ = cref.rasterize_frame(centers, colors, np.float32(g.opacity), conics, vals, r16, rs, bg,
+                                                  pixel_offset=0.5, margin=1e-4)
     rng = np.random.default_rng(3)
     wimg = rng.normal(size=(rs[0], rs[1], 3)).astype(np.float32)
+    wimg[fragile.astype(bool)] = 0.0         # no gradient flows through pixels fp32 may decide differently
     image, d_colors, d_centers, d_conics, d_opac = gs.gpu_rasterize(
         gpu_ctx, None, None, centers, colors, g.opacity, conics, b, training=True, result_size=rs, tile_size=32,
         background_color=bg, dL_dimage=wimg, pixel_offset=0.5)
+    _check_image(image, refc, fragile, f"{name} tile 32")
     p = {k: torch.tensor(np.asarray(d[k], dtype=np.float32).astype(np.float64), requires_grad=True)
          for k in ("in_center", "in_scaling", "in_rotation", "in_sh", "in_opacity")}
     img, aux = ref_torch.render(p["in_center"], p["in_scaling"], p["in_rotation"], p["in_sh"], p["in_opacity"],
@@ -549,12 +561,11 @@ def test_tile_size_32_render_path(gpu_ctx, name):
     for k in ("centers", "conics", "colors"):
         aux[k].retain_grad()
     (img * torch.tensor(wimg, dtype=torch.float64)).sum().backward()
-    ref = img.detach().numpy()
-    err = np.abs(image - ref)
-    assert (err > IMG_ATOL + IMG_RTOL * np.abs(ref)).mean() < 5e-3 and err.max() < 0.02   # rare branch flips only
-    _assert_grad(d_colors, aux["colors"].grad.numpy(), "d_colors t32", tol=2e-3)
-    _assert_grad(d_conics, aux["conics"].grad.numpy(), "d_conics t32", tol=2e-3)
-    _assert_grad(d_opac, p["in_opacity"].grad.numpy(), "d_opacity t32", tol=2e-3)
+    assert np.abs(img.detach().numpy() - refc)[~fragile.astype(bool)].max() < 2e-5     # the two oracles agree
+    _assert_grad(d_colors, aux["colors"].grad.numpy(), "d_colors t32")
+    _assert_grad(d_conics, aux["conics"].grad.numpy(), "d_conics t32")
+    _assert_grad(d_opac, p["in_opacity"].grad.numpy(), "d_opacity t32")
+    _assert_grad(d_centers / np.array([.5 * rs[0], .5 * rs[1]]), aux["centers"].grad.numpy(), "d_centers t32")
 
 
 def test_preprocess_batch_equals_single_view_calls(gpu_ctx):
@@ -789,7 +800,8 @@ def _adversarial_2d(seed, W, H):
 def test_blend_adversarial_inputs_vs_oracles(gpu_ctx, seed, tile):
     """K6/K7 on inputs placed on their decision boundaries, every gaussian listed in every tile: image,
     last contributors and T_final against the C restatement (reference's lists), the culled lists give the
-    same image, gradients against fp64 autograd of the restated blend."""
+    same image, gradients within 1e-4 (normwise) of fp64 autograd of the restated blend, with dL/dimage
+    zeroed on the oracle's fragile pixels (up to a third of them here, by construction)."""
     import torch
     import gsplat_amd as gs
     W, H = 96, 80
@@ -826,6 +838,7 @@ def test_blend_adversarial_inputs_vs_oracles(gpu_ctx, seed, tile):
     # gradients: fp64 autograd of the restated blend over the same lists
     rng = np.random.default_rng(seed + 10)
     wimg = rng.normal(size=(W, H, 3)).astype(np.float32)
+    wimg[fragile.astype(bool)] = 0.0      # no gradient through pixels where fp32 may take the other branch
     p = [torch.tensor(a.astype(np.float64), requires_grad=True) for a in (cen, col, opa, con)]
     ref_img = ref_torch.blend(p[0], p[1], p[2], p[3], exact.vals.cpu().numpy(), exact.ranges.cpu().numpy(), rs, tile,
                               bg, 0.5)
@@ -838,10 +851,7 @@ def test_blend_adversarial_inputs_vs_oracles(gpu_ctx, seed, tile):
                                 (d_con, p[3].grad, "conics")):
             g, w = got.cpu().numpy().astype(np.float64), want.numpy()
             assert np.all(np.isfinite(g)), what
-            # branch flips at the placed discontinuities move single pixels: a few per cent of the largest entry
-            assert np.abs(g - w).max() <= 0.05 * np.abs(w).max(), (what, np.abs(g - w).max(), np.abs(w).max())
-            close = np.abs(g - w) <= 2e-3 * np.abs(w).max()
-            assert close.mean() > 0.9, (what, close.mean())
+            _assert_grad(g, w, f"adversarial {what}", tol=ADV_TOL)
 
 
 def test_record_writing_preprocess_equals_array_path(gpu_ctx):
@@ -879,8 +889,8 @@ def test_extreme_parameters_stay_finite_and_match_autograd(gpu_ctx):
     """Parameters at the edges of what the path accepts -- needle and pancake scales, un-normalised
     quaternions (norm 1e-3 .. 1e3), gaussians behind / on the near plane / far outside the frustum,
     opacities at 0, 1e-3, .99 and 1, strongly negative SH (clamped colours) -- through K1 -> culled
-    binning -> K6 -> K7 -> K8: everything finite, parameter gradients within a loose bar of fp64
-    autograd (the branch flips such inputs provoke move single pixels)."""
+    binning -> K6 -> K7 -> K8: everything finite, parameter gradients within 1e-4 (normwise) of fp64
+    autograd with dL/dimage zeroed on the pixels the fp64 oracle flags as fragile."""
     import torch
     import gsplat_amd as gs
     W, H = 160, 112
@@ -900,6 +910,15 @@ def test_extreme_parameters_stay_finite_and_match_autograd(gpu_ctx):
     image, st = pipe.forward(view)
     assert bool(torch.isfinite(image).all()) and bool(torch.isfinite(st["t_final"]).all())
     wimg = rng.normal(size=(W, H, 3)).astype(np.float32)
+    # fragile pixels (fp64 C oracle on the reference's lists of the same fp32 2D inputs) carry no gradient
+    ex = gs.SplatPipeline(g, rs, opacity_is_logit=False, background=(.3, .2, .1), ctx=gpu_ctx, cull_tiles=False)
+    _, se = ex.forward(view)
+    _, _, _, fragile, _ = cref.rasterize_frame(se["centers"].cpu().numpy(), se["colors"].cpu().numpy(),
+                                               se["opac"].cpu().numpy(), se["conics"].cpu().numpy(),
+                                               se["binning"].vals.cpu().numpy(), se["binning"].ranges.cpu().numpy(), rs,
+                                               (.3, .2, .1), pixel_offset=0.5, margin=1e-4)
+    assert fragile.mean() < 0.05
+    wimg[fragile.astype(bool)] = 0.0
     grads = gs.FlatGrads(pipe.N, image.device)
     pipe.backward(st, torch.tensor(wimg, device=image.device), grads, accumulate=False)
     assert bool(torch.isfinite(grads.flat).all())
@@ -911,9 +930,7 @@ def test_extreme_parameters_stay_finite_and_match_autograd(gpu_ctx):
         fin = np.isfinite(ref)
         assert fin.mean() > 0.99, k
         gv = gt.cpu().numpy().astype(np.float64)
-        scale = np.abs(ref[fin]).max()
-        close = np.abs(gv - ref)[fin] <= 2e-3 * scale
-        assert close.mean() > 0.995 and np.abs(gv - ref)[fin].max() <= 0.05 * scale, (k, close.mean(), np.abs(gv - ref)[fin].max(), scale)
+        _assert_grad(gv[fin], ref[fin], f"extreme {k}", tol=ADV_TOL)
 
 
 @pytest.mark.parametrize("N,W,H", [(1, 8, 8), (2, 16, 16), (63, 17, 33), (64, 40, 16), (65, 33, 17), (257, 64, 48),
