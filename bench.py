@@ -108,10 +108,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # a collective that does not complete within the timeout ends this rank with a non-zero exit (RCCL: the
+        # process group's watchdog aborts the communicator; gloo: the call raises) instead of hanging the job
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("GS_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=limit)
     dev = torch.device("cuda", local_rank)
 
     W, H, N = args.width, args.height, args.gaussians

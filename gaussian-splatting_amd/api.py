@@ -62,6 +62,25 @@ class DeviceContext:
             check(self.lib.gs_ctx_set_stream(self.handle, ctypes.c_void_p(sid)), "gs_ctx_set_stream")
             self._stream_id = sid
 
+    # streams and sibling contexts are handed out by the context, so that everything above it (SplatPipeline,
+    # train_step) names no device runtime: a context of another kind can stand in this slot
+    def clone(self):
+        """A second context (own workspace arena) on the same device."""
+        return DeviceContext(self.device_index)
+
+    def new_stream(self):
+        return torch.cuda.Stream(self.device)
+
+    def current_stream(self):
+        return torch.cuda.current_stream(self.device)
+
+    def use_stream(self, stream):
+        """Context manager: `stream` is the current stream inside the block."""
+        return torch.cuda.stream(stream)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
     def set_option(self, name, value):
         check(self.lib.gs_ctx_set_option(self.handle, name.encode(), int(value)), "gs_ctx_set_option")
 
@@ -114,6 +133,8 @@ def _ctx(ctx):
     if isinstance(ctx, DeviceContext):
         return ctx
     if ctx is not None:
+        if all(hasattr(ctx, a) for a in ("lib", "handle", "device", "sync_stream", "clone", "new_stream")):
+            return ctx            # a context of another kind with DeviceContext's interface
         raise TypeError("ctx must be the DeviceContext returned by setup_gpu() (or None)")
     dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
     if dev not in _default_ctx:

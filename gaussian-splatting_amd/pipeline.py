@@ -98,14 +98,14 @@ class SplatPipeline:
         lane owns its workspace arena and stream, so one view's blend tail overlaps another view's
         preprocess/binning.  The parameters are shared (read-only during a step)."""
         while len(self._lanes) < n:
-            self._lanes.append((api.DeviceContext(self.ctx.device_index), torch.cuda.Stream(self.ctx.device)))
+            self._lanes.append((self.ctx.clone(), self.ctx.new_stream()))
         return self._lanes[:n]
 
     def alt_contexts(self, n):
         """A second DeviceContext (workspace) per lane, main stream included: with two, a lane can
         count the tiles of its next view while the current view's records are still in use."""
         while len(self._alts) < n:
-            self._alts.append(api.DeviceContext(self.ctx.device_index))
+            self._alts.append(self.ctx.clone())
         return self._alts[:n]
 
     def contexts(self):
@@ -260,22 +260,29 @@ class SplatPipeline:
         state["rows"] = rows
         return rows
 
-    def backward_params(self, states, grads, accumulate=False, ctx=None):
+    def backward_params(self, states, grads, accumulate=False, ctx=None, g_range=None):
         """K8 over every view in `states` at once (each must have been through backward_rows):
-        parameters are read once and the gradients written (or added) once."""
+        parameters are read once and the gradients written (or added) once.  g_range=(g0, g1) restricts
+        the launch to those gaussians (every array of the call is per-gaussian and contiguous, so a range
+        is the same call on offset pointers); g0 must be a multiple of 4 (16-byte aligned rows of every
+        array)."""
         c = ctx or self.ctx
         c.sync_stream()
+        g0, g1 = (0, self.N) if g_range is None else (int(g_range[0]), int(g_range[1]))
+        if not (0 <= g0 <= g1 <= self.N) or g0 % 4:
+            raise ValueError(f"g_range {g_range} must lie in [0, {self.N}] and start at a multiple of 4")
+        at = lambda t, width: ctypes.c_void_p(t.data_ptr() + g0 * width * t.element_size())
         views = (GsViewBackward * max(len(states), 1))()
         for k, st in enumerate(states):
             views[k].cam = ctypes.pointer(st["cam"])
-            views[k].radii = st["radii"].data_ptr()
-            views[k].clamped = st["clamped"].data_ptr()
-            views[k].grad_rows = st["rows"].data_ptr()
+            views[k].radii = at(st["radii"], 1).value
+            views[k].clamped = at(st["clamped"], 3).value
+            views[k].grad_rows = at(st["rows"], 16).value
         check(c.lib.gs_backward_params_batch(
-            c.handle, self.N, api._ptr(self.means), api._ptr(self.log_scales), api._ptr(self.quats),
-            api._ptr(self.sh), api._ptr(self.opacity), int(self.opacity_is_logit), len(states), views,
-            int(bool(accumulate)), api._ptr(grads.means), api._ptr(grads.log_scales), api._ptr(grads.quats),
-            api._ptr(grads.opacity), api._ptr(grads.sh)), "gs_backward_params_batch")
+            c.handle, g1 - g0, at(self.means, 3), at(self.log_scales, 3), at(self.quats, 4),
+            at(self.sh, 48), at(self.opacity, 1), int(self.opacity_is_logit), len(states), views,
+            int(bool(accumulate)), at(grads.means, 3), at(grads.log_scales, 3), at(grads.quats, 4),
+            at(grads.opacity, 1), at(grads.sh, 48)), "gs_backward_params_batch")
         return grads
 
     def backward(self, state, dL_dimage, grads, accumulate=True):
@@ -323,7 +330,7 @@ class Optimizer:
 def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale):
     """Forward, loss gradient and K7 of this rank's views on n_lanes concurrent lanes.  Returns
     (states, done events per view, lanes)."""
-    main = torch.cuda.current_stream(pipe.ctx.device)
+    main = pipe.ctx.current_stream()
     # a process has 4 hardware queues (GPU_MAX_HW_QUEUES): up to 3 side lanes, the main stream is the 4th
     if n_lanes > 3:
         lanes = pipe.lanes(n_lanes - 1) + [(pipe.ctx, main)]
@@ -350,7 +357,7 @@ def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, sca
         ctx, stream = lanes[k % n_lanes]
         if (k // n_lanes) & 1:
             ctx = alts[k % n_lanes]
-        with torch.cuda.stream(stream):
+        with pipe.ctx.use_stream(stream):
             if k >= first:
                 stream.wait_event(pre_ready)
             tokens[k] = pipe.forward_begin(views[mine[k]], ctx=ctx, pre=pres[k])
@@ -364,12 +371,12 @@ def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, sca
         ks = range(r0, min(r0 + n_lanes, len(mine)))
         fwd = {}
         for k in ks:
-            with torch.cuda.stream(lanes[k % n_lanes][1]):
+            with pipe.ctx.use_stream(lanes[k % n_lanes][1]):
                 fwd[k] = pipe.forward_finish(tokens.pop(k), after_blend=lambda k=k: begin(k + n_lanes))
         for k in ks:
             stream = lanes[k % n_lanes][1]
             image, state = fwd[k]
-            with torch.cuda.stream(stream):
+            with pipe.ctx.use_stream(stream):
                 dL, _ = pipe.image_loss(image, targets[mine[k]], loss_kind, scale, losses[k:k + 1], ctx=state["ctx"])
                 pipe.backward_rows(state, dL)
                 done.append(stream.record_event())
@@ -377,42 +384,56 @@ def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, sca
     return states, done, lanes
 
 
+def gaussian_chunks(N, n_chunks):
+    """[g0, g1) ranges covering N gaussians in about n_chunks pieces; every g0 is a multiple of 256."""
+    step = max(256, (-(-N // max(int(n_chunks), 1)) + 255) // 256 * 256)
+    return [(g0, min(g0 + step, N)) for g0 in range(0, N, step)] or [(0, 0)]
+
+
+def _all_reduce(pipe, tensors, works):
+    """SUM all-reduce of every tensor in `tensors` over the default process group.  RCCL ("nccl"): the
+    collectives are stream-ordered behind what the current stream holds and run on the communicator's own
+    stream, so they are issued asynchronously and `works` collects their handles (wait on them before the
+    gradients are used): later kernels on the current stream overlap them.  Host-staged back ends (gloo):
+    issued on an idle device and blocking.  Measured on MI355X with two ranks sharing one GPU: a gloo
+    all-reduce of a device tensor issued while the rank's lane streams still held work never completed
+    (the same collective alone, or behind a device synchronisation, completes in 135 ms for 236 MB)."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        for t in tensors:
+            works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+        return
+    if tensors and tensors[0].device.type != "cpu":
+        pipe.ctx.synchronize()
+    for t in tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,
-               k8_early_lanes=None):
-    """Forward+backward over this rank's shard of `views`, then one all-reduce of the flat gradient
+               k8_early_lanes=None, allreduce_chunks=4):
+    """Forward+backward over this rank's shard of `views`, then the all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
     formed together with dL/dimage by the fused native kernel.  concurrent_views > 1 renders that
     many local views at a time on separate streams (the 4th is the main stream).  The views of the
     first k8_early_lanes lanes (default: half of them) get their parameter backward as soon as they are
-    complete, under the blend kernels of the lanes still running.  Returns (sum of local losses as a
-    device scalar, number of local views)."""
+    complete, under the blend kernels of the lanes still running.  With more than one rank the last
+    parameter-backward launch runs over `allreduce_chunks` ranges of gaussians, and the SH gradients of a
+    range (48 of the 59 floats per gaussian) are all-reduced while the next range is computed; the other
+    four groups follow as one slice.  Returns (sum of local losses as a device scalar, number of local
+    views)."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1
     mine = shard_views(len(views), rank, world)
-    W, H = pipe.result_size
     scale = 1.0 if loss_scale is None else loss_scale
     states = []
-    n_lanes = min(int(concurrent_views), len(mine)) if hasattr(pipe, "lanes") else 1
-    if not hasattr(pipe, "image_loss"):        # duck-typed stand-ins (CPU tests): plain torch MSE
-        loss = torch.zeros((), dtype=torch.float32, device=pipe.ctx.device)
-        gscale = scale * 2.0 / (W * H * 3)
-        for v in mine:
-            image, state = pipe.forward(views[v])
-            diff = image - targets[v]
-            loss = loss + (diff * diff).mean()
-            pipe.backward_rows(state, diff * gscale)
-            states.append(state)
-        pipe.backward_params(states, grads, accumulate=False)
-        if distributed and world > 1:
-            dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
-        return loss, len(mine)
+    n_lanes = min(int(concurrent_views), len(mine))
     losses = torch.zeros(max(len(mine), 1), dtype=torch.float32, device=pipe.ctx.device)
     late = None
     if n_lanes > 1:
-        main = torch.cuda.current_stream(pipe.ctx.device)
+        main = pipe.ctx.current_stream()
         states, done, lanes = _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale)
         # The lanes do not finish together (the hardware serves the queues in a fixed order): K8 of the
         # early lanes' views runs on lane 0's stream while the others still blend.
@@ -421,7 +442,7 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
         early = [k for k in range(len(mine)) if k % n_lanes < k8_early_lanes]
         if states_hook is None and 2 <= len(early) < len(mine):
             ctx0, stream0 = lanes[0]
-            with torch.cuda.stream(stream0):
+            with pipe.ctx.use_stream(stream0):
                 for k in early:
                     stream0.wait_event(done[k])
                 pipe.backward_params([states[k] for k in early], grads, accumulate=False, ctx=ctx0)
@@ -439,10 +460,16 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     if states_hook is not None:      # e.g. Densifier.accumulate: per-view blend gradients are still alive here
         states_hook(states)
     # one pass over the gaussians for the (remaining) local views; writes, or adds to the early launch
-    if late is None:
-        pipe.backward_params(states, grads, accumulate=False)
-    else:
-        pipe.backward_params(late, grads, accumulate=True)
-    if distributed and world > 1:
-        dist.all_reduce(grads.flat, op=dist.ReduceOp.SUM)
+    last, accumulate = (states, False) if late is None else (late, True)
+    if not (distributed and world > 1):
+        pipe.backward_params(last, grads, accumulate=accumulate)
+        return loss, len(mine)
+    offs, _ = flat_offsets(pipe.N)
+    works = []
+    for g0, g1 in gaussian_chunks(pipe.N, allreduce_chunks):
+        pipe.backward_params(last, grads, accumulate=accumulate, g_range=(g0, g1))
+        _all_reduce(pipe, [grads.flat[offs[4] + 48 * g0:offs[4] + 48 * g1]], works)
+    _all_reduce(pipe, [grads.flat[:offs[4]]], works)      # means, log-scales, quaternions, opacity: 11 floats each
+    for w in works:
+        w.wait()                                          # the current stream waits for the communicator's
     return loss, len(mine)
