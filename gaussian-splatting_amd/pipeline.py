@@ -461,7 +461,7 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
         states_hook(states)
     # one pass over the gaussians for the (remaining) local views; writes, or adds to the early launch
     last, accumulate = (states, False) if late is None else (late, True)
-    if not (distributed and world > 1):
+    if not distributed:          # (a one-rank group takes the collective path too: it costs three more launches)
         pipe.backward_params(last, grads, accumulate=accumulate)
         return loss, len(mine)
     offs, _ = flat_offsets(pipe.N)

@@ -254,3 +254,36 @@ def test_parameter_backward_of_an_empty_view_batch_writes_zeros(gpu_ctx):
     grads.flat.fill_(3.0)
     loss, n = gs.train_step(pipe, [], [], grads)
     assert n == 0 and float(grads.means.abs().max()) == 0.0
+
+
+def test_step_under_a_one_rank_rccl_group_equals_the_plain_step(gpu_ctx):
+    """The collective path of train_step on the device: chunked K8 + asynchronous RCCL all-reduces of the
+    slices + waits, under a one-rank "nccl" process group (a 1-GPU box cannot host two RCCL ranks; with one
+    rank the reduction is the identity, so the gradients must equal the plain step's)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    import gsplat_amd as gs
+    W, H = 320, 240
+    cam, R, t, g, rs = synth_scene(5000, W, H, seed=31, fx=200.0)
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    views = [gs.View(cam, R, np.array([0.05 * k, -0.02 * k, 0.1 * k])) for k in range(5)]
+    gen = torch.Generator(device="cpu").manual_seed(31)
+    targets = [torch.rand(W, H, 3, generator=gen).to(gpu_ctx.device) for _ in views]
+    plain = gs.FlatGrads(pipe.N, gpu_ctx.device)
+    loss_p, _ = gs.train_step(pipe, views, targets, plain, concurrent_views=4)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_ctx.device)
+    try:
+        coll = gs.FlatGrads(pipe.N, gpu_ctx.device)
+        coll.flat.fill_(5.0)
+        for _ in range(2):
+            loss_c, n = gs.train_step(pipe, views, targets, coll, concurrent_views=4, allreduce_chunks=4)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert n == 5 and abs(float(loss_c) - float(loss_p)) <= 1e-6 * float(loss_p)
+    scale = float(plain.flat.abs().max())
+    assert scale > 0 and float((coll.flat - plain.flat).abs().max()) <= 2e-5 * scale
