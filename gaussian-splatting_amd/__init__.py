@@ -5,7 +5,7 @@ ABI in include/gsplat.h.  The directory name is not a Python identifier: import 
 `gsplat_amd` alias module at the repo root (or importlib.import_module("gaussian-splatting_amd"))."""
 from ._lib import GsError, LIB_PATH, SIGNATURES, load as load_library   # noqa: F401
 from .api import (DeviceContext, GaussianSet, KernelLibrary, TileBinning, backward_pass, c_rasterize,   # noqa: F401
-                  forward_pass, gpu_rasterize, match_gaus_to_tiles, rasterize, setup_gpu)
+                  forward_pass, gpu_rasterize, match_gaus_to_tiles, rasterize, setup_gpu, view_stats)
 from .pipeline import (FlatGrads, flat_offsets, gaussian_chunks, Optimizer, REFERENCE_LEARNING_RATES, SplatPipeline, View, shard_views,   # noqa: F401
                        train_step)
 from .io import (gaussians_from_point_cloud, knn_distances, load_data, load_gaussians, qvec2rotmat,   # noqa: F401

@@ -30,6 +30,14 @@ class GsViewRecords(ctypes.Structure):
                 ("records", "depths", "clamped", "tiles_touched", "radii")]
 
 
+class GsStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in
+                ("n_gaussians", "n_visible", "duplicates", "visited", "max_tile_list", "nonempty_tiles", "tiles",
+                 "pixels", "pixels_broke", "bytes_preprocess", "bytes_depth_sort", "bytes_duplicate",
+                 "bytes_tile_sort", "bytes_ranges", "bytes_blend_forward", "bytes_blend_backward",
+                 "bytes_param_backward")]
+
+
 class GsError(RuntimeError):
     pass
 
@@ -75,6 +83,7 @@ SIGNATURES = {
                                               _I32, _I32, _I32, _F, _P, _P, _P, _P]),
     "gs_backward_params_batch": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, _I32,
                                                 ctypes.POINTER(GsViewBackward), _I32, _P, _P, _P, _P, _P]),
+    "gs_view_stats": (ctypes.c_int, [_P, _I32, _P, _I64, _P, _I32, _I32, _I32, _P, ctypes.POINTER(GsStats)]),
     "gs_image_loss": (ctypes.c_int, [_P, _I64, _P, _P, _I32, _F, _I32, _P, _P]),
     "gs_adam_step": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.POINTER(_F * 5),
                                     _F, _F, _F, _I32, _I32, _F]),

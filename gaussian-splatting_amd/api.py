@@ -449,6 +449,19 @@ def blend_backward(c, centers, colors, opacities, conics, binning, bg, pixel_off
     return d_centers, d_conics, d_opac, d_colors
 
 
+def view_stats(ctx, radii, binning, n_contrib):
+    """gs_view_stats: N_visible, D, D* (visited), longest tile list and the algorithmic bytes per stage of one
+    rendered view, computed by the library from device arrays (any of them may be None).  Returns a dict."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    st = _lib.GsStats()
+    W, H = binning.result_size
+    N = int(radii.shape[0]) if radii is not None else 0
+    check(c.lib.gs_view_stats(c.handle, N, _ptr(radii), binning.D, _ptr(binning.ranges), W, H, binning.tile_size,
+                              _ptr(n_contrib), ctypes.byref(st)), "gs_view_stats")
+    return {name: int(getattr(st, name)) for name, _ in st._fields_}
+
+
 def _blend_inputs(c, centers, colors, opacities, conics):
     dev = c.device
     N = len(centers)

@@ -19,6 +19,7 @@ SOURCES = {
     "param_bwd.hip": [],
     "tile_shim.hip": [],
     "train.hip": [],
+    "stats.hip": [],
 }
 
 

@@ -595,6 +595,26 @@ int bits_of(uint32_t v) {
 
 }  // namespace
 
+int gs_radix_sort_pairs(gs_ctx *ctx, uint32_t n, const uint32_t *keys_in, const int32_t *vals_in, int bits,
+                        uint32_t *keys[2], int32_t *vals[2], const uint32_t **k_out, const int32_t **v_out) {
+    if (bits < 1) bits = 1;
+    const int passes = (bits + 7) / 8;
+    const int per_pass = (bits + passes - 1) / passes;
+    const uint32_t *kin = keys_in;
+    const int32_t *vin = vals_in;
+    for (int p = 0; p < passes; p++) {
+        const int shift = p * per_pass;
+        const int nbits = bits - shift < per_pass ? bits - shift : per_pass;
+        const int rc = radix_pass(ctx, n, kin, vin, keys[p & 1], vals[p & 1], shift, nbits);
+        if (rc) return rc;
+        kin = keys[p & 1];
+        vin = vals[p & 1];
+    }
+    *k_out = kin;
+    *v_out = vin;
+    return GS_OK;
+}
+
 namespace {
 
 // rec == nullptr: the reference's rect semantics; otherwise pairs are culled with the box test.

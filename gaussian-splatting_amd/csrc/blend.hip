@@ -562,11 +562,18 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 #ifndef GS_BWD_WAVES
 #define GS_BWD_WAVES 5
 #endif
+// DET (ctx option deterministic_backward): instead of adding a (tile, gaussian) partial into the gaussian's row
+// with float atomics, the wave stores it at the position of the list entry it belongs to -- det_out[sub][pos][12],
+// sub = which 16x16 block of the caller's tile (tiles larger than 16 share one list between their blocks) -- and
+// det_reduce_kernel adds up each gaussian's partials in list order.
+constexpr int DET_ROW = 12;    // floats per partial: 9 used, 48 bytes = three float4s
+template <bool DET>
 __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_kernel(QuadArgs a,
                                                                          const int32_t *__restrict__ n_contrib,
                                                                          const float *__restrict__ t_final,
                                                                          const float *__restrict__ dL_dimage,
-                                                                         float *__restrict__ grad_rows) {
+                                                                         float *__restrict__ grad_rows,
+                                                                         float *__restrict__ det_out, int64_t det_D) {
     // per wave: 64 staged records of 12 words (geo | con | rgb).  Once entry j has been processed
     // its record is dead, so lane 63 parks the 9 reduced gradients in place: geo.xyzw, con.xyzw,
     // rgb.x; rgb.w keeps the gaussian id for the flush.
@@ -741,7 +748,10 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                 reinterpret_cast<float *>(&s_geo[j])[lane >> 4] = x0 * sc0;
                 reinterpret_cast<float *>(&s_con[j])[lane >> 4] = x1 * sc1;
             }
-            if (lane == 63) s_rgb[j].x = g_b;
+            if (lane == 63) {
+                s_rgb[j].x = g_b;
+                if (DET) s_rgb[j].y = __int_as_float(idx);     // the colour is dead: keep the entry's list position
+            }
         }
         wave_lds_fence();
         // flush: one 64-byte row per gaussian, 4 rows per wave-instruction, lanes 0..8 of each
@@ -750,8 +760,16 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
         for (int e0 = 0; e0 < n; e0 += 4) {
             const int e = e0 + (lane >> 4);
             if (e < n && comp < 9 && ((touched >> e) & 1ull)) {
-                const int gid = __float_as_int(s_rgb[e].w);
-                atomicAdd(&grad_rows[(size_t)gid * GRAD_ROW + comp], s_flat[(comp >> 2) * 256 + e * 4 + (comp & 3)]);
+                const float v = s_flat[(comp >> 2) * 256 + e * 4 + (comp & 3)];
+                if (DET) {
+                    const int m = (1 << a.shift) - 1;
+                    const int64_t sub = (int64_t)((tx & m) << a.shift | (ty & m));
+                    const int64_t pos = (int64_t)rg.x + __float_as_int(s_rgb[e].y);
+                    det_out[(sub * det_D + pos) * DET_ROW + comp] = v;
+                } else {
+                    const int gid = __float_as_int(s_rgb[e].w);
+                    atomicAdd(&grad_rows[(size_t)gid * GRAD_ROW + comp], v);
+                }
             }
         }
     }
@@ -767,6 +785,26 @@ extern "C" int gs_debug_read_stamps(int which, unsigned long long *host, int nti
                                     hipMemcpyDeviceToHost);
 }
 #endif
+
+// Deterministic backward, stage 2: the list positions sorted by gaussian id (stable, so ascending inside a run).
+// One 16-lane group per sorted element; the group at the head of a gaussian's run walks the run and adds the
+// partials of every sub-block in that fixed order, lanes 0..8 one component each, then stores the row.
+__global__ __launch_bounds__(256) void det_reduce_kernel(int64_t D, int nsub, const uint32_t *__restrict__ gid_sorted,
+                                                         const int32_t *__restrict__ pos_sorted,
+                                                         const float *__restrict__ det, float *__restrict__ grad_rows) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int comp = threadIdx.x & 15;
+    if (i >= D) return;
+    const uint32_t g = gid_sorted[i];
+    if (i > 0 && gid_sorted[i - 1] == g) return;      // not the head of its run
+    if (comp >= 9) return;
+    float sum = 0.0f;
+    for (int64_t j = i; j < D && gid_sorted[j] == g; j++) {
+        const int64_t pos = pos_sorted[j];
+        for (int sub = 0; sub < nsub; sub++) sum += det[((int64_t)sub * D + pos) * DET_ROW + comp];
+    }
+    grad_rows[(size_t)g * GRAD_ROW + comp] = sum;
+}
 
 // grad rows -> the reference's four arrays (gpu_rasterize return tuple, rasterization.py:105)
 __global__ __launch_bounds__(256) void unpack_rows_kernel(int N, const float *__restrict__ rows,
@@ -885,20 +923,59 @@ extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, co
 
 namespace {
 
+// Deterministic form of K7 (ctx option deterministic_backward): partials next to the list entries, entries sorted
+// by gaussian, runs summed in list order.  `rows` has been zeroed by the caller.
+int blend_backward_deterministic(gs_ctx *ctx, const QuadArgs &q, const BlendArgs &a, int32_t N, int64_t D, int tiles,
+                                 const int32_t *n_contrib, const float *t_final, const float *dL_dimage, float *rows) {
+    GS_REQUIRE(a.shift <= 1, "deterministic_backward supports tile_size 16 and 32 (got %d)", TILE << a.shift);
+    GS_REQUIRE(D < (1ll << 31), "deterministic_backward: D=%lld exceeds 2^31-1", (long long)D);
+    int rc;
+    const int nsub = 1 << (2 * a.shift);
+    const size_t d4 = ((size_t)D * 4 + 255) & ~(size_t)255;
+    if ((rc = gs_buf_reserve(ctx, &ctx->det_partials, (size_t)nsub * D * DET_ROW * sizeof(float)))) return rc;
+    if ((rc = gs_buf_reserve(ctx, &ctx->det_sort, 4 * d4))) return rc;
+    float *det = (float *)ctx->det_partials.p;
+    char *ds = (char *)ctx->det_sort.p;
+    uint32_t *keys[2] = {(uint32_t *)ds, (uint32_t *)(ds + d4)};
+    int32_t *pos[2] = {(int32_t *)(ds + 2 * d4), (int32_t *)(ds + 3 * d4)};
+    GS_HIP(hipMemsetAsync(det, 0, (size_t)nsub * D * DET_ROW * sizeof(float), ctx->stream));
+    gs_prof_scope prof_(ctx, GS_K_BLEND_BWD);
+    hipLaunchKernelGGL(blend_bwd_quad_kernel<true>, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0,
+                       ctx->stream, q, n_contrib, t_final, dL_dimage, rows, det, D);
+    GS_HIP(hipGetLastError());
+    int bits = 1;
+    while (bits < 32 && (1ll << bits) < (long long)N) bits++;
+    const uint32_t *k_sorted = nullptr;
+    const int32_t *p_sorted = nullptr;
+    if ((rc = gs_radix_sort_pairs(ctx, (uint32_t)D, reinterpret_cast<const uint32_t *>(q.vals), nullptr, bits, keys, pos,
+                                  &k_sorted, &p_sorted)))
+        return rc;
+    const int64_t threads = D * 16;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, D, nsub,
+                       k_sorted, p_sorted, (const float *)det, rows);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 // launches K7 into `rows` ([N][16], zeroed here)
 int blend_backward_into_rows(gs_ctx *ctx, const BlendArgs &a, int32_t N, int64_t D, int tiles,
                              const int32_t *n_contrib, const float *t_final, const float *dL_dimage, float *rows) {
     int rc;
     GS_HIP(hipMemsetAsync(rows, 0, (size_t)N * GRAD_ROW * sizeof(float), ctx->stream));
     if (D <= 0) return GS_OK;
-    switch (ctx->ext_records ? 4 : ctx->ppt) {    // records are read by the quad kernel only (see gs_blend_forward)
+    // records are read by the quad kernel only (see gs_blend_forward); so is the deterministic form
+    switch ((ctx->ext_records || ctx->deterministic_bwd) ? 4 : ctx->ppt) {
         case 1: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<1>, dim3(tiles), dim3(256), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
         case 2: { gs_prof_scope prof_(ctx, GS_K_BLEND_BWD); hipLaunchKernelGGL(blend_bwd_kernel<2>, dim3(tiles), dim3(128), 0, ctx->stream, a, n_contrib, t_final, dL_dimage, rows); } break;
         default: {
             QuadArgs q;
             if ((rc = fill_quad(q, a, ctx, N, true))) return rc;
+            if (ctx->deterministic_bwd) {
+                if ((rc = blend_backward_deterministic(ctx, q, a, N, D, tiles, n_contrib, t_final, dL_dimage, rows))) return rc;
+                break;
+            }
             gs_prof_scope prof_(ctx, GS_K_BLEND_BWD);
-            hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
+            hipLaunchKernelGGL(blend_bwd_quad_kernel<false>, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows, (float *)nullptr, (int64_t)0);
         } break;
     }
     GS_HIP(hipGetLastError());
@@ -1013,8 +1090,8 @@ extern "C" int gs_blend_backward_noalloc(gs_ctx *ctx, int32_t N, const float *ce
         q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
         q.list_tiles_y = a.list_tiles_y; q.shift = a.shift;
         q.ntiles = tiles;
-        hipLaunchKernelGGL(blend_bwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0,
-                           ctx->stream, q, n_contrib, t_final, dL_dimage, rows);
+        hipLaunchKernelGGL(blend_bwd_quad_kernel<false>, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0,
+                           ctx->stream, q, n_contrib, t_final, dL_dimage, rows, (float *)nullptr, (int64_t)0);
     }
     hipLaunchKernelGGL(unpack_rows_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, (const float *)rows,
                        dL_dcenters, dL_dconics, dL_dopacities, dL_dcolors);

@@ -60,6 +60,9 @@ struct gs_ctx {
     gs_buf grad_rows;    // float[N][16] 64-byte gradient rows for blend backward
     gs_buf tile_scratch; // rasterize_tile shim staging
     gs_buf loss_partials; // f64[1024] per-block loss sums
+    gs_buf stats_words;   // u64[8] counters of gs_view_stats
+    gs_buf det_partials;  // deterministic backward: float[nsub][D][12] per-(tile, gaussian) partial gradients
+    gs_buf det_sort;      // deterministic backward: 2 x u32[D] keys + 2 x i32[D] positions (sort by gaussian)
     uint64_t *total_host = nullptr;   // pinned, 2 words
     hipEvent_t count_event = nullptr; // recorded behind the copy of D into total_host (gs_bin_count*_begin)
     int32_t count_pending_N = -1;     // N of a gs_bin_count*_begin whose gs_bin_count_end has not run
@@ -69,6 +72,7 @@ struct gs_ctx {
     std::vector<gs_prof_span> prof_spans;     // recorded, not yet read
     std::vector<hipEvent_t> prof_free;        // recycled events
     int ppt = 4;         // pixels per thread of the blend kernels (1, 2 or 4)
+    bool deterministic_bwd = false;   // option deterministic_backward
     int32_t bin_N = -1;
     int64_t bin_D = -1;
     uint32_t bin_max_depth = 0;
@@ -84,6 +88,11 @@ struct gs_ctx {
 int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);
 // blend.hip: looks up this device's copy of the static scratch array (gs_blend_backward_noalloc); device must be current
 int gs_scratch_setup(int device);
+// binning.hip: stable LSD radix sort of n (u32 key, i32 value) pairs on the low `bits` bits; values start as 0..n-1
+// when vals_in is NULL.  keys[2] / vals[2] are ping-pong buffers of n elements each; *k_out / *v_out name the
+// buffers that hold the result.
+int gs_radix_sort_pairs(gs_ctx *ctx, uint32_t n, const uint32_t *keys_in, const int32_t *vals_in, int bits,
+                        uint32_t *keys[2], int32_t *vals[2], const uint32_t **k_out, const int32_t **v_out);
 
 // brackets the launches issued during its lifetime with two events on the ctx stream
 struct gs_prof_scope {

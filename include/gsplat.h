@@ -44,7 +44,13 @@ int gs_ctx_set_stream(gs_ctx *ctx, void *stream);
 int gs_ctx_destroy(gs_ctx *ctx);
 /* Tuning knobs (no reference counterpart).  "pixels_per_thread": 1, 2 or 4 pixels of a tile
  * column per thread in the blend kernels (default 4 = one wavefront per 16x16 tile; also read
- * from the environment variable GSPLAT_PPT at ctx creation). */
+ * from the environment variable GSPLAT_PPT at ctx creation).
+ * "deterministic_backward": 1 = gs_blend_backward* sum the per-(tile, gaussian) partial gradients in a
+ * fixed order instead of with float atomics (the reference's kernel accumulates with compare-and-swap
+ * atomics in arrival order, setup_gpu.py:9-21): the wave of a tile stores its partials next to the
+ * tile's list entries, the entries are sorted by gaussian and each gaussian's run is added up in list
+ * order.  Bitwise reproducible from run to run; about three times the time of the atomics form and
+ * 48 bytes of workspace per list entry.  tile_size 16 or 32 only; one-wave-per-tile kernels only. */
 int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value);
 /* Per-kernel timing with HIP events on the ctx stream (no reference counterpart; the reference
  * only prints perf_counter deltas per stage, train.py:29-60).  While enabled every kernel launch
@@ -245,6 +251,26 @@ int gs_backward_params_batch(gs_ctx *ctx, int32_t N, const float *means, const f
                              int32_t opacity_is_logit, int32_t n_views, const gs_view_backward *views,
                              int32_t accumulate, float *dL_dmeans, float *dL_dlog_scales,
                              float *dL_dquats, float *dL_dopacity, float *dL_dsh);
+
+/* Workload statistics of one rendered view (no counterpart in the reference, which only prints per-stage
+ * wall times, train.py:29-60, gaussian.py:45-51).  Computed by small reduction kernels from the arrays the
+ * hot path produced: radii[N] (gs_preprocess), ranges[tiles,2] and D (gs_bin_fill*), n_contrib[W,H]
+ * (gs_blend_forward); any of the three may be NULL (its fields are then -1).  Synchronises the ctx's stream.
+ * `visited` is D* of SURVEY section 8(d): per 16x16 pixel block the deepest last-contributor, summed -- the
+ * list entries the blend kernels walk before early-out; the bytes_* fields are the per-launch ALGORITHMIC
+ * bytes of section 8(d) (fp32, degree-3 SH, split depth / tile sort) for these sizes. */
+typedef struct gs_stats {
+    int64_t n_gaussians, n_visible;          /* radii > 0 */
+    int64_t duplicates;                      /* D: (gaussian, tile) pairs in the lists */
+    int64_t visited;                         /* D* */
+    int64_t max_tile_list, nonempty_tiles, tiles;
+    int64_t pixels, pixels_broke;            /* pixels that left the loop through T < 1e-4 (rasterize.c:118) */
+    int64_t bytes_preprocess, bytes_depth_sort, bytes_duplicate, bytes_tile_sort, bytes_ranges;
+    int64_t bytes_blend_forward, bytes_blend_backward, bytes_param_backward;
+} gs_stats;
+int gs_view_stats(gs_ctx *ctx, int32_t N, const int32_t *radii, int64_t D, const int32_t *ranges,
+                  int32_t res_w, int32_t res_h, int32_t tile_size, const int32_t *n_contrib,
+                  gs_stats *out_host);
 
 /* Training-loop side.
  * gs_image_loss replaces train.py:45-49 (an L1 "loss" on uint8 copies that wraps around, defect

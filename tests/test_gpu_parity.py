@@ -973,3 +973,64 @@ def test_tiny_sizes_and_wave_boundaries(gpu_ctx, N, W, H):
         assert abs(float(loss) - total) <= 1e-5 * max(total, 1e-6)
         scale = float(single.flat.abs().max())
         assert float((multi.flat - single.flat).abs().max()) <= 2e-5 * max(scale, 1e-12)
+
+
+@pytest.mark.parametrize("tile", [16, 32])
+def test_deterministic_backward_is_bitwise_reproducible_and_equals_the_atomics_form(gpu_ctx, tile):
+    """ctx option deterministic_backward: K7 stores its per-(tile, gaussian) partials next to the list entries and
+    each gaussian's run is summed in list order (the reference accumulates with CAS atomics in arrival order,
+    setup_gpu.py:9-21).  Three runs agree bit for bit; the atomics form agrees to rounding; parameter gradients
+    through the pipeline are reproducible too."""
+    import torch
+    import gsplat_amd as gs
+    d = as_record(*dense_scene(), bg=(.2, .1, .3))
+    cam, R, t, g, rs, bg = scene_inputs(d)
+    out = gs.forward_pass(gpu_ctx, None, None, cam, R, t, g, result_size=rs, tile_size=tile, training=False)
+    centers, depths, colors, conics, tiles_touched, radii = out
+    b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tiles_touched, radii, depths, result_size=rs, tile_size=tile)
+    wimg = np.random.default_rng(4).normal(size=(rs[0], rs[1], 3)).astype(np.float32)
+    run = lambda: gs.gpu_rasterize(gpu_ctx, None, None, centers, colors, g.opacity, conics, b, training=True,
+                                   result_size=rs, tile_size=tile, background_color=bg, dL_dimage=wimg)[1:]
+    atomics = run()
+    gpu_ctx.set_option("deterministic_backward", 1)
+    try:
+        det = [run() for _ in range(3)]
+        pipe = gs.SplatPipeline(g, rs, tile_size=tile, background=bg, opacity_is_logit=False, ctx=gpu_ctx)
+        flats = []
+        for _ in range(2):
+            image, st = pipe.forward(gs.View(cam, R, t))
+            gr = gs.FlatGrads(pipe.N, gpu_ctx.device)
+            pipe.backward(st, torch.from_numpy(wimg).to(gpu_ctx.device), gr, accumulate=False)
+            flats.append(gr.flat.clone())
+    finally:
+        gpu_ctx.set_option("deterministic_backward", 0)
+    for k in range(4):
+        assert np.array_equal(det[0][k], det[1][k]) and np.array_equal(det[0][k], det[2][k])
+        _assert_grad(det[0][k], atomics[k], f"deterministic vs atomics [{k}]", tol=1e-5)
+    assert torch.equal(flats[0], flats[1]) and float(flats[0].abs().max()) > 0
+
+
+def test_view_stats_from_the_library_match_a_recomputation(gpu_ctx):
+    """gs_view_stats against the same quantities recomputed with torch ops (what bench.py used to do)."""
+    import torch
+    import gsplat_amd as gs
+    W, H = 333, 211
+    cam, R, t, g, rs = synth_scene(20_000, W, H, seed=12, log_scale=(1.0, 3.5))
+    g.center[:50, 2] = -1.0                                   # behind the camera: not visible
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    image, st = pipe.forward(gs.View(cam, R, t))
+    b = st["binning"]
+    s = gs.view_stats(gpu_ctx, st["radii"], b, st["n_contrib"])
+    lens = (b.ranges[:, 1] - b.ranges[:, 0]).long()
+    nc = (st["n_contrib"] & 0x7FFFFFFF).long()
+    pad = torch.zeros(b.tiles_x * 16, b.tiles_y * 16, dtype=torch.int64, device=nc.device)
+    pad[:W, :H] = nc
+    visited = int(pad.view(b.tiles_x, 16, b.tiles_y, 16).amax(dim=(1, 3)).sum())
+    assert s["n_gaussians"] == 20_000 and s["n_visible"] == int((st["radii"] > 0).sum()) <= 20_000 - 50
+    assert s["duplicates"] == b.D == int(lens.sum())
+    assert s["max_tile_list"] == int(lens.max()) and s["nonempty_tiles"] == int((lens > 0).sum())
+    assert s["visited"] == visited and 0 < visited <= b.D
+    assert s["pixels"] == W * H and s["pixels_broke"] == int((st["n_contrib"] < 0).sum())
+    assert s["bytes_blend_backward"] == visited * 76 + W * H * 20 and s["bytes_tile_sort"] == 40 * b.D
+    only = gs.view_stats(gpu_ctx, None, b, None)
+    assert only["n_visible"] == -1 and only["visited"] == -1 and only["max_tile_list"] == s["max_tile_list"]

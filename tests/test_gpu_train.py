@@ -201,6 +201,14 @@ def test_densify_clone_split_prune(gpu_ctx):
     pipe2 = run(3)[0]
     assert float((pipe.means - pipe2.means).abs().max()) < 1e-4
     assert float((pipe.means - run(4)[0].means).abs().max()) > 1e-3
+    # with the ordered reduction in K7 (ctx option deterministic_backward) the whole update is bit-reproducible
+    gpu_ctx.set_option("deterministic_backward", 1)
+    try:
+        a, b = run(3)[0], run(3)[0]
+    finally:
+        gpu_ctx.set_option("deterministic_backward", 0)
+    for name in ("means", "log_scales", "quats", "opacity", "sh"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
     # still renders and trains with the new N
     grads = gs.FlatGrads(pipe.N, gpu_ctx.device)
     image, st = pipe.forward(gs.View(cam, R, t))
