@@ -527,6 +527,13 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
                     tT = brk ? 0.0f : tT;
                     thr[k] = brk ? 0.0f : thr[k];
                     last[k] = brk ? __float_as_int(co.w) : last[k];
+#ifndef GS_NO_QUADRANT_RETIRE
+                    // the quadrant's last pixel has finished: the rest of this batch skips it (scalar bitmaps)
+                    if (!wave_any(thr[k] != 0.0f)) {
+                        live[k] = 0ull;
+                        rem &= live[0] | live[1] | live[2] | live[3] | (1ull << j);
+                    }
+#endif
                 }
                 C[k][0] = __builtin_fmaf(rgb.x, w, C[k][0]);
                 C[k][1] = __builtin_fmaf(rgb.y, w, C[k][1]);
