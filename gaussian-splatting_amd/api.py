@@ -68,8 +68,9 @@ class DeviceContext:
         """A second context (own workspace arena) on the same device."""
         return DeviceContext(self.device_index)
 
-    def new_stream(self):
-        return torch.cuda.Stream(self.device)
+    def new_stream(self, priority=0):
+        """A new stream; priority -1 = served before the default-priority streams by the hardware dispatcher."""
+        return torch.cuda.Stream(self.device, priority=priority)
 
     def current_stream(self):
         return torch.cuda.current_stream(self.device)

@@ -354,6 +354,7 @@ struct QuadArgs {
     int W, H, tiles_y, ntiles;
     int list_tiles_y, shift;
     float pixel_offset;
+    const int32_t *order;    // launch slot -> 16x16 block, heaviest first (NULL: spatial order)
 };
 
 // four threads per gaussian, one float4 of the record each: stores are fully coalesced
@@ -436,8 +437,9 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
     __shared__ unsigned s_qm_[QUAD_WAVES][64];
 
     const int wv = threadIdx.x >> 6;
-    const int tile = blockIdx.x * QUAD_WAVES + wv;
-    if (tile >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
+    const int slot = blockIdx.x * QUAD_WAVES + wv;
+    if (slot >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
+    const int tile = a.order ? a.order[slot] : slot;
     GS_STAMP_BEGIN();
     float4 *s_geo = s_rec_[wv][0], *s_con = s_rec_[wv][1], *s_rgb = s_rec_[wv][2];
     unsigned *s_qm = s_qm_[wv];
@@ -588,8 +590,9 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     __shared__ unsigned s_qm_[QUAD_WAVES][64];
 
     const int wv = threadIdx.x >> 6;
-    const int tile = blockIdx.x * QUAD_WAVES + wv;
-    if (tile >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
+    const int slot = blockIdx.x * QUAD_WAVES + wv;
+    if (slot >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
+    const int tile = a.order ? a.order[slot] : slot;
     GS_STAMP_BEGIN();
     float4 *s_geo = s_rec_[wv][0], *s_con = s_rec_[wv][1], *s_rgb = s_rec_[wv][2];
     const float *s_flat = reinterpret_cast<const float *>(s_rec_[wv]);
@@ -793,6 +796,79 @@ extern "C" int gs_debug_read_stamps(int which, unsigned long long *host, int nti
 }
 #endif
 
+// ------------------------------------------------------------------ heaviest tiles first (K7)
+// A blend kernel's duration alone on the chip is set by the life of its waves, not by its throughput: a wave walks
+// its tile's list at its own pace whatever else is resident, and the 8160 tiles of a 1080p frame do not fit the
+// chip's wave slots at once (5 per SIMD in K7), so the tiles dispatched last run on an emptying chip (measured with
+// tools/stamp_blend.py: the last waves of a blend kernel start when the first finish).  K7's launch slots are
+// therefore handed out heaviest-first -- the tiles that start late are the short ones -- by the deepest
+// last-contributor of the tile's pixels, i.e. what K6 actually visited: 0.51 -> 0.41 ms per 1080p view alone on the
+// chip.  (Inside a 4-lane training step other lanes' kernels fill those tails anyway and the step time does not
+// move; at 32 400 tiles (4K) a launch is many rounds deep and the order changes nothing; K6 has no such estimate
+// before it runs -- the list length is a poor one (early termination decides) and costs locality: not ordered.)
+// One 1024-thread workgroup counting-sorts the tiles into 1024 work classes.
+__device__ __forceinline__ int work_class(int w) {            // fine below 512 entries, 16-entry classes above
+    return w < 512 ? w : 512 + min((w - 512) >> 4, 511);
+}
+
+// work[tile] <- deepest last-contributor over the 16x16 block (one wave per block, as the K7 prologue reads it)
+__global__ __launch_bounds__(256) void tile_visited_kernel(int ntiles, int tiles_y, int W, int H,
+                                                           const int32_t *__restrict__ n_contrib,
+                                                           int32_t *__restrict__ work) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x & 63;
+    const int tx = tile / tiles_y, ty = tile % tiles_y;
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int px = tx * TILE + (lane >> 2), py = ty * TILE + (lane & 3) * 4 + k;
+        if (px < W && py < H) m = max(m, n_contrib[(size_t)px * H + py] & 0x7fffffff);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if (lane == 0) work[tile] = m;
+}
+
+// order[slot] <- tile, by descending work class.  work == NULL: the work of a tile is the length of its list.
+__global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int tiles_y, int list_tiles_y, int shift,
+                                                          const int2 *__restrict__ ranges,
+                                                          const int32_t *__restrict__ work,
+                                                          int32_t *__restrict__ order) {
+    __shared__ uint32_t s_hist[1024];
+    __shared__ uint32_t s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    auto cls = [&](int tile) {
+        int w;
+        if (work) {
+            w = work[tile];
+        } else {
+            const int tx = tile / tiles_y, ty = tile % tiles_y;
+            const int2 r = ranges[(tx >> shift) * list_tiles_y + (ty >> shift)];
+            w = r.y - r.x;
+        }
+        return 1023 - work_class(w);           // heaviest class first
+    };
+    s_hist[t] = 0u;
+    __syncthreads();
+    for (int i = t; i < ntiles; i += 1024) atomicAdd(&s_hist[cls(i)], 1u);
+    __syncthreads();
+    uint32_t v = s_hist[t], inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    __syncthreads();
+    s_hist[t] = base + inc - v;                // first slot of class t
+    __syncthreads();
+    for (int i = t; i < ntiles; i += 1024) order[atomicAdd(&s_hist[cls(i)], 1u)] = i;
+}
+
 // Deterministic backward, stage 2: the list positions sorted by gaussian id (stable, so ascending inside a run).
 // One 16-lane group per sorted element; the group at the head of a gaussian's run walks the run and adds the
 // partials of every sub-block in that fixed order, lanes 0..8 one component each, then stores the row.
@@ -842,6 +918,23 @@ int fill_quad(QuadArgs &q, const BlendArgs &a, gs_ctx *ctx, int32_t N, bool reus
     q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
     q.list_tiles_y = a.list_tiles_y; q.shift = a.shift;
     q.ntiles = gs_div_up(a.W, TILE) * a.tiles_y;
+    q.order = nullptr;
+    return GS_OK;
+}
+
+// order[slot] -> tile, heaviest first, into the ctx's buffer (option tile_order, on by default), by what the forward
+// pass visited; n_contrib == NULL: by list length.  Only where a launch is one to three rounds of wave slots deep.
+int order_tiles(gs_ctx *ctx, QuadArgs &q, const int32_t *n_contrib) {
+    if (!ctx->tile_order || q.ntiles < ctx->tile_order_min || q.ntiles > ctx->tile_order_max) return GS_OK;
+    int rc;
+    if ((rc = gs_buf_reserve(ctx, &ctx->tile_order_buf, (size_t)q.ntiles * 2 * sizeof(int32_t)))) return rc;
+    int32_t *order = (int32_t *)ctx->tile_order_buf.p, *work = order + q.ntiles;
+    if (n_contrib)
+        hipLaunchKernelGGL(tile_visited_kernel, dim3(gs_div_up(q.ntiles, 4)), dim3(256), 0, ctx->stream, q.ntiles,
+                           q.tiles_y, q.W, q.H, n_contrib, work);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, q.ntiles, q.tiles_y, q.list_tiles_y,
+                       q.shift, q.ranges, n_contrib ? (const int32_t *)work : (const int32_t *)nullptr, order);
+    q.order = order;
     return GS_OK;
 }
 
@@ -982,6 +1075,7 @@ int blend_backward_into_rows(gs_ctx *ctx, const BlendArgs &a, int32_t N, int64_t
                 break;
             }
             gs_prof_scope prof_(ctx, GS_K_BLEND_BWD);
+            if ((rc = order_tiles(ctx, q, n_contrib))) return rc;
             hipLaunchKernelGGL(blend_bwd_quad_kernel<false>, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, n_contrib, t_final, dL_dimage, rows, (float *)nullptr, (int64_t)0);
         } break;
     }
@@ -1097,6 +1191,7 @@ extern "C" int gs_blend_backward_noalloc(gs_ctx *ctx, int32_t N, const float *ce
         q.W = a.W; q.H = a.H; q.tiles_y = a.tiles_y; q.pixel_offset = a.pixel_offset;
         q.list_tiles_y = a.list_tiles_y; q.shift = a.shift;
         q.ntiles = tiles;
+        q.order = nullptr;       // spatial order: the ordering pass would need a buffer
         hipLaunchKernelGGL(blend_bwd_quad_kernel<false>, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0,
                            ctx->stream, q, n_contrib, t_final, dL_dimage, rows, (float *)nullptr, (int64_t)0);
     }

@@ -73,6 +73,9 @@ struct gs_ctx {
     std::vector<hipEvent_t> prof_free;        // recycled events
     int ppt = 4;         // pixels per thread of the blend kernels (1, 2 or 4)
     bool deterministic_bwd = false;   // option deterministic_backward
+    bool tile_order = true;           // option tile_order: blend kernels take their tiles heaviest first
+    int tile_order_min = 2048, tile_order_max = 16384;   // ... for frames with this many 16x16 blocks
+    gs_buf tile_order_buf;            // i32[ntiles] launch order + i32[ntiles] work per tile
     int32_t bin_N = -1;
     int64_t bin_D = -1;
     uint32_t bin_max_depth = 0;

@@ -50,6 +50,7 @@ extern "C" int gs_ctx_create(int device, void *stream, gs_ctx **out) {
         delete c;
         return gs_set_error(GS_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
     }
+    if (const char *e = getenv("GSPLAT_TILE_ORDER")) c->tile_order = atoi(e) != 0;
     if (const char *e = getenv("GSPLAT_PPT")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4) c->ppt = v;
@@ -68,6 +69,11 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
     if (strcmp(name, "deterministic_backward") == 0) {
         GS_REQUIRE(value == 0 || value == 1, "deterministic_backward must be 0 or 1 (got %d)", value);
         ctx->deterministic_bwd = value != 0;
+        return GS_OK;
+    }
+    if (strcmp(name, "tile_order") == 0) {
+        GS_REQUIRE(value == 0 || value == 1, "tile_order must be 0 or 1 (got %d)", value);
+        ctx->tile_order = value != 0;
         return GS_OK;
     }
     if (strcmp(name, "profile_mask") == 0) {   // bit i: time kernel id i (gs_profile_kernel_name) when profiling is on
@@ -157,7 +163,8 @@ extern "C" int gs_ctx_destroy(gs_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     gs_buf *bufs[] = {&ctx->counts, &ctx->offsets, &ctx->block_sums, &ctx->total, &ctx->depth_sort,
                       &ctx->keys_tmp, &ctx->vals_tmp, &ctx->radix_table, &ctx->packed, &ctx->grad_rows,
-                      &ctx->tile_scratch, &ctx->loss_partials, &ctx->stats_words, &ctx->det_partials, &ctx->det_sort};
+                      &ctx->tile_scratch, &ctx->loss_partials, &ctx->stats_words, &ctx->det_partials, &ctx->det_sort,
+                      &ctx->tile_order_buf};
     for (gs_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (gs_prof_span &sp : ctx->prof_spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }

@@ -201,25 +201,40 @@ class SplatPipeline:
 
     def forward_finish(self, tok, want_keys=False, after_blend=None):
         """Waits for the tile count, then sort -> K6.  after_blend() (if given) runs right after K6 is
-        enqueued: train_step uses it to launch the lane's NEXT count before this view's loss and K7."""
-        c, pre, opac = tok["c"], tok["pre"], tok["opac"]
+        enqueued: the lane scheduler uses it to launch the lane's NEXT count before this view's loss and K7."""
+        self.forward_bin(tok, want_keys=want_keys)
+        out = self.forward_blend(tok)
+        if after_blend is not None:
+            after_blend()
+        return out
+
+    def forward_bin(self, tok, want_keys=False):
+        """Second stage of a view: waits for its tile count (one host wait), then the sorts and the tile
+        ranges, on the ctx the count was launched on."""
+        c, pre = tok["c"], tok["pre"]
         c.sync_stream()
-        cam, centers, depths, colors, conics = pre["cam"], pre["centers"], pre["depths"], pre["colors"], pre["conics"]
-        clamped, rect, radii = pre["clamped"], pre["rect"], pre["radii"]
         # the records are a per-call binding: whatever raises in between (D >= 2^31, out of memory), the ctx
         # does not keep a pointer to tensors this call owns
         with _records(c, self.N, pre.get("rec")):
             if tok["bin"] is not None:
-                binning = api.bin_culled_finish(tok["bin"], want_keys=want_keys)
+                tok["binning"] = api.bin_culled_finish(tok["bin"], want_keys=want_keys)
             else:
-                binning = api.match_gaus_to_tiles(c, None, None, rect, radii, depths, self.result_size,
-                                                  self.tile_size, want_keys=want_keys)
-            image, n_contrib, t_final = api.blend_forward(c, centers, colors, opac, conics, binning, self.bg,
-                                                          self.pixel_offset)
-        if after_blend is not None:
-            after_blend()
-        state = dict(ctx=c, cam=cam, depths=depths, centers=centers, colors=colors, conics=conics, clamped=clamped,
-                     radii=radii, opac=opac, binning=binning, n_contrib=n_contrib, t_final=t_final, rec=pre.get("rec"))
+                tok["binning"] = api.match_gaus_to_tiles(c, None, None, pre["rect"], pre["radii"], pre["depths"],
+                                                         self.result_size, self.tile_size, want_keys=want_keys)
+        return tok["binning"]
+
+    def forward_blend(self, tok, ctx=None):
+        """Third stage: K6 over the lists of forward_bin, on `ctx` (default: the ctx that binned the view; a
+        scheduler that bins on one stream and blends on another passes the blend lane's ctx)."""
+        pre, opac, binning = tok["pre"], tok["opac"], tok["binning"]
+        c = ctx or tok["c"]
+        c.sync_stream()
+        with _records(c, self.N, pre.get("rec")):
+            image, n_contrib, t_final = api.blend_forward(c, pre["centers"], pre["colors"], opac, pre["conics"],
+                                                          binning, self.bg, self.pixel_offset)
+        state = dict(ctx=c, cam=pre["cam"], depths=pre["depths"], centers=pre["centers"], colors=pre["colors"],
+                     conics=pre["conics"], clamped=pre["clamped"], radii=pre["radii"], opac=opac, binning=binning,
+                     n_contrib=n_contrib, t_final=t_final, rec=pre.get("rec"))
         self.stats = dict(D=binning.D)
         return image, state
 
@@ -456,20 +471,20 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
             dL, _ = pipe.image_loss(image, targets[v], loss_kind, scale, losses[k:k + 1])
             pipe.backward_rows(state, dL)
             states.append(state)
-    loss = losses.sum()
     if states_hook is not None:      # e.g. Densifier.accumulate: per-view blend gradients are still alive here
         states_hook(states)
     # one pass over the gaussians for the (remaining) local views; writes, or adds to the early launch
     last, accumulate = (states, False) if late is None else (late, True)
     if not distributed:          # (a one-rank group takes the collective path too: it costs three more launches)
         pipe.backward_params(last, grads, accumulate=accumulate)
-        return loss, len(mine)
-    offs, _ = flat_offsets(pipe.N)
-    works = []
-    for g0, g1 in gaussian_chunks(pipe.N, allreduce_chunks):
-        pipe.backward_params(last, grads, accumulate=accumulate, g_range=(g0, g1))
-        _all_reduce(pipe, [grads.flat[offs[4] + 48 * g0:offs[4] + 48 * g1]], works)
-    _all_reduce(pipe, [grads.flat[:offs[4]]], works)      # means, log-scales, quaternions, opacity: 11 floats each
-    for w in works:
-        w.wait()                                          # the current stream waits for the communicator's
+    else:
+        offs, _ = flat_offsets(pipe.N)
+        works = []
+        for g0, g1 in gaussian_chunks(pipe.N, allreduce_chunks):
+            pipe.backward_params(last, grads, accumulate=accumulate, g_range=(g0, g1))
+            _all_reduce(pipe, [grads.flat[offs[4] + 48 * g0:offs[4] + 48 * g1]], works)
+        _all_reduce(pipe, [grads.flat[:offs[4]]], works)      # means, log-scales, quaternions, opacity: 11 floats each
+        for w in works:
+            w.wait()                                          # the current stream waits for the communicator's
+    loss = losses.sum()
     return loss, len(mine)

@@ -50,7 +50,10 @@ int gs_ctx_destroy(gs_ctx *ctx);
  * atomics in arrival order, setup_gpu.py:9-21): the wave of a tile stores its partials next to the
  * tile's list entries, the entries are sorted by gaussian and each gaussian's run is added up in list
  * order.  Bitwise reproducible from run to run; about three times the time of the atomics form and
- * 48 bytes of workspace per list entry.  tile_size 16 or 32 only; one-wave-per-tile kernels only. */
+ * 48 bytes of workspace per list entry.  tile_size 16 or 32 only; one-wave-per-tile kernels only.
+ * "tile_order": 1 (default; also GSPLAT_TILE_ORDER) = gs_blend_backward* hand their launch slots to the
+ * 16x16 blocks heaviest-first (by the deepest last-contributor of the block, from n_contrib), for frames
+ * of 2048..16384 blocks; results are unchanged (float atomics arrive in another order). */
 int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value);
 /* Per-kernel timing with HIP events on the ctx stream (no reference counterpart; the reference
  * only prints perf_counter deltas per stage, train.py:29-60).  While enabled every kernel launch

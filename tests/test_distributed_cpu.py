@@ -127,7 +127,7 @@ class FakeCtx:
     def clone(self):
         return FakeCtx(self.lib)
 
-    def new_stream(self):
+    def new_stream(self, priority=0):
         return FakeStream()
 
     def current_stream(self):
