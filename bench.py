@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--log-scale", type=float, nargs=2, default=(1.0, 3.0))
     ap.add_argument("--cpu-views", type=int, default=32, help="frames rendered by the CPU baseline (about 0.4 s each on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-lists", action="store_true", help="skip the timed step on the reference's own lists")
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the single-stream per-kernel timing pass")
     ap.add_argument("--kernel-timing", choices=["dominant", "all", "none"], default="dominant",
                     help="which kernels get HIP events inside the timed region")
     ap.add_argument("--k8-early-lanes", type=int, default=None,
@@ -52,6 +54,18 @@ def parse():
     ap.add_argument("--concurrent-views", type=int, default=4, help="local views in flight on separate streams")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: single-view forward render")
     return ap.parse_args()
+
+
+def source_sha16():
+    """Hash of the kernel sources and the build recipe: ties a PMC summary under profiles/ to the tree it was
+    collected from (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "gaussian-splatting_amd", "csrc")
+    for name in sorted(os.listdir(src)) + ["../build.py", "../../include/gsplat.h"]:
+        with open(os.path.join(src, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def make_scene(N, W, H, log_scale, seed=20240601):
@@ -191,66 +205,92 @@ def main():
     mpix = n_views * W * H / 1e6
     value = mpix / (ms_per_step / 1e3)
 
-    # ---- workload statistics on this rank's first view (outside the timed region)
+    # ---- workload statistics of this rank's first view, from the library (gs_view_stats; outside the timed region)
     image, st = pipe.forward(views[mine[0] if mine else 0])
     torch.cuda.synchronize()
-    D = st["binning"].D
-    ranges = st["binning"].ranges
-    lens = (ranges[:, 1] - ranges[:, 0]).to(torch.int64)
-    tiles_x, tiles_y = st["binning"].tiles_x, st["binning"].tiles_y
-    nc = (st["n_contrib"] & 0x7FFFFFFF).to(torch.int64)
-    pad = torch.zeros(tiles_x * 16, tiles_y * 16, dtype=torch.int64, device=dev)
-    pad[:W, :H] = nc
-    per_tile_visited = pad.view(tiles_x, 16, tiles_y, 16).amax(dim=(1, 3)).reshape(-1)
-    d_star = int(per_tile_visited.sum().item())           # duplicates visited before early-out
-    pairs = int((per_tile_visited * 256).sum().item())
-    n_visible = int((st["radii"] > 0).sum().item())
-    max_len = int(lens.max().item())
-
-    # ---- roofline of the dominant kernel (largest share of the timed region)
+    stats = gs.view_stats(ctx, st["radii"], st["binning"], st["n_contrib"])
+    D, d_star, n_visible, max_len = stats["duplicates"], stats["visited"], stats["n_visible"], stats["max_tile_list"]
     P = W * H
-    alg_bytes = {   # SURVEY.md 8(d) per-launch algorithmic bytes
-        "preprocess": N * (236 + 56),
-        # tile sort: 2 passes x D x (4 histogram read + 8 read + 8 write); depth sort likewise over N
-        "bin_sort": 2 * D * 20,
-        "bin_depth_sort": 2 * N * 20,
-        "bin_duplicate": N * 28 + D * 8,
-        "blend_forward": d_star * 40 + P * 20,
-        "blend_backward": d_star * 40 + P * 20 + d_star * 36,
-        "param_backward": N * (236 + 36) + N * 236,
+
+    # ---- every kernel ALONE on the chip: one stream, HIP events of the library around each launch.  These are
+    # the durations a rocprofv3 --kernel-trace of tools/one_view.py shows (profiles/), and the ones the roofline
+    # uses: inside the step a kernel shares the chip with three other lanes and its span says little about it.
+    single = {}
+    if not args.forward_only and not args.no_single_stream:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_times
+        single, _ = kernel_times.measure(pipe, views, targets[0], min(4, len(views)), repeats=2)
+    alg_bytes = {   # SURVEY.md 8(d) algorithmic bytes per launch, as gs_view_stats prices them for these sizes
+        "preprocess": stats["bytes_preprocess"], "bin_sort": stats["bytes_tile_sort"],
+        "bin_depth_sort": stats["bytes_depth_sort"], "bin_duplicate": stats["bytes_duplicate"],
+        "bin_ranges": stats["bytes_ranges"], "blend_forward": stats["bytes_blend_forward"],
+        "blend_backward": stats["bytes_blend_backward"],
     }
     timed = {k: v for k, v in prof.items() if v[1] > 0}
-    dom = max(timed, key=lambda k: timed[k][0]) if timed else None
+    kernels = {k: {"ms_per_launch_in_step": round(v[0] / v[1], 4), "launches": int(v[1])} for k, v in timed.items()}
+    for k, v in single.items():
+        kernels.setdefault(k, {})["ms_per_launch_alone"] = round(v["ms_per_launch"], 4)
+    # dominant kernel: the largest share of a view's single-stream time (blend backward; forward when --forward-only)
+    if single:
+        dom = max((k for k in single if k in alg_bytes), key=lambda k: single[k]["ms_per_launch"] * single[k]["launches"])
+    else:
+        dom = max(timed, key=lambda k: timed[k][0]) if timed else None
     roofline = None
-    kernels = {k: {"ms_per_launch": round(v[0] / v[1], 4), "launches": int(v[1])} for k, v in timed.items()}
     if dom:
-        dur_s = timed[dom][0] / timed[dom][1] / 1e3
+        dur_ms = single[dom]["ms_per_launch"] if dom in single else timed[dom][0] / timed[dom][1]
         ab = alg_bytes.get(dom)
-        achieved = ab / dur_s / 1e9 if ab else None
+        achieved = ab / (dur_ms / 1e3) / 1e9 if ab else None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2) if achieved else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": None,
-                    "avg_launch_ms": round(dur_s * 1e3, 4), "algorithmic_bytes_per_launch": int(ab) if ab else None,
-                    "note": "blend kernels are FP32-VALU bound (no dense contraction, no MFMA); "
-                            "valu_* fields price the same launch against the vector-FP32 peak"}
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
-        # separately with rocprofv3 --pmc on the same scene (tools/one_view.py, tools/pmc_summary.py)
+                    "avg_launch_ms": round(dur_ms, 4),
+                    "avg_launch_source": "HIP events around the launch, kernel alone on the chip (one stream)"
+                    if dom in single else "HIP events around the launch inside the timed region",
+                    "algorithmic_bytes_per_launch": int(ab) if ab else None,
+                    "note": "the blend kernels are bound by vector-instruction issue, not by HBM or MFMA (no dense "
+                            "contraction): valu_issue_frac prices the counted wave-instructions at 2 cycles each"}
+        if dom in timed:
+            roofline["in_step_launch_ms"] = round(timed[dom][0] / timed[dom][1], 4)
+        # HBM bytes and instruction counts per launch from the PMC passes of THIS source tree (tools/pmc_collect.sh,
+        # tools/pmc_summary.py): refused when the kernels have changed since, or for another workload
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            if N == 1_000_000 and (W, H) == (1920, 1080) and dom in pmc and "hbm_traffic_bytes" in pmc[dom]:
-                roofline["traffic"] = int(pmc[dom]["hbm_traffic_bytes"])
-                roofline["traffic_source"] = "profiles/r01_pmc_summary.json"
-                # avg_launch_ms above is measured while four views share the GPU; the same kernel alone:
-                roofline["single_stream_launch_ms"] = round(pmc[dom]["avg_duration_us_under_pmc"] / 1e3, 4)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            same_tree = pmc.get("_meta", {}).get("source_sha16") == source_sha16()
+            same_load = (N, W, H) == (1_000_000, 1920, 1080) and tuple(args.log_scale) == (1.0, 3.0)
+            if same_tree and same_load and dom in pmc:
+                e = pmc[dom]
+                if "hbm_traffic_bytes" in e:
+                    roofline["traffic"] = int(e["hbm_traffic_bytes"])
+                    roofline["traffic_source"] = "profiles/r02_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+                if "valu_issue_frac" in e:
+                    roofline["valu_issue_frac"] = e["valu_issue_frac"]
+                    roofline["salu_issue_frac"] = e.get("salu_issue_frac")
+                    roofline["valu_wave_instructions"] = int(e["SQ_INSTS_VALU"])
+                    roofline["counter_clock_ghz"] = e.get("clock_ghz")
+            elif not same_tree:
+                roofline["traffic_source"] = "none: profiles/r02_pmc_summary.json was collected from another source tree"
         except (OSError, ValueError):
             pass
-        if dom in ("blend_forward", "blend_backward"):
-            flop_per_pair = 26 if dom == "blend_forward" else 70
-            tf = pairs * flop_per_pair / dur_s / 1e12
-            roofline.update({"valu_pair_evals_per_s": round(pairs / dur_s / 1e9, 3),
-                             "valu_unit": "Gpairs/s", "valu_tflops_est": round(tf, 2),
-                             "valu_peak_tflops": FP32_VALU_PEAK_TFLOPS,
-                             "valu_frac_est": round(tf / FP32_VALU_PEAK_TFLOPS, 4)})
+
+    # ---- the bit-exact list path (cull_tiles=False: the reference's own (tile, depth) lists), same step
+    exact_lists = None
+    if rank == 0 and world == 1 and not args.forward_only and not args.no_exact_lists:
+        exact_pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx, cull_tiles=False)
+        run = lambda: gs.train_step(exact_pipe, views, targets, grads, concurrent_views=args.concurrent_views,
+                                    k8_early_lanes=args.k8_early_lanes)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) * 1e3 / args.steps
+        _, se = exact_pipe.forward(views[0])
+        exact_lists = {"ms_per_step": round(ms, 3), "value": round(mpix / (ms / 1e3), 2), "unit": "Mpix/s",
+                       "duplicates_D": int(se["binning"].D),
+                       "note": "SplatPipeline(cull_tiles=False): keys, values and ranges bit-exact against the reference"}
+        del exact_pipe, se
 
     # ---- CPU baseline: restatement of rasterize.c on the host cores (rank 0, N=1 only), bounded sample
     cpu_baseline = None
@@ -276,25 +316,34 @@ def main():
                         "cores": int(used), "kind": "port",
                         "sample": f"{n_cpu_views} views {W}x{H}, forward blend only (the reference's rasterize.c has no "
                                   f"backward), same scene, the reference's tile lists (D={d_exact}), fp64 POSIX restatement of rasterize.c, "
-                                  f"OpenMP over tiles, {cpu_s:.2f} s wall on {int(used)} threads; host has "
+                                  f"OpenMP over tiles, built with gcc -O2 -fopenmp -ffp-contract=off (no -march=native: "
+                                  f"oracle/Makefile), {cpu_s:.2f} s wall on {int(used)} threads; host has "
                                   f"{os.cpu_count()} logical CPUs"}
 
     if rank == 0:
+        res = "%dx%d" % (W, H)
+        what = "%s gaussians %s" % (("%dM" % (N // 1_000_000)) if N % 1_000_000 == 0 else str(N), "1080p" if (W, H) == (1920, 1080) else res)
+        is_cfg2 = (N, W, H) == (1_000_000, 1920, 1080) and tuple(args.log_scale) == (1.0, 3.0)
+        if args.forward_only:
+            workload = "%ssingle %s view forward, %d gaussians" % ("configs[1]: " if is_cfg2 else "", res, N)
+        else:
+            workload = ("%sfwd+bwd training step, %d gaussians, %d views per GPU per step at %s (global batch %d views "
+                        "sharded over %d rank(s)), RCCL all-reduce of [N*59] fp32 grads"
+                        % ("configs[2]: " if is_cfg2 and len(mine) == 8 else "", N, len(mine), res, n_views, world))
         out = {
-            "metric": "Mpix/s fwd+bwd at 1M gaussians 1080p" if not args.forward_only else "Mpix/s forward at 1M gaussians 1080p",
+            "metric": ("Mpix/s fwd+bwd at " if not args.forward_only else "Mpix/s forward at ") + what,
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[2]: fwd+bwd training step, %d gaussians, %d views per GPU per step at %dx%d "
-                                    "(global batch %d views sharded over %d rank(s)), RCCL all-reduce of [N*59] fp32 grads"
-                                    % (N, len(mine), W, H, n_views, world)) if not args.forward_only else
-                                   "configs[1]: single %dx%d view forward, %d gaussians" % (W, H, N),
+            "config": {"workload": workload,
                        "gaussians": N, "views_per_step": n_views, "width": W, "height": H, "tile": 16,
                        "log_scale_range": list(args.log_scale), "seed": 20240601,
+                       "view_set": "yaw (k-3.5)*1.5 deg, pitch ((3k mod n)-3.5)*0.6 deg about the origin: every gaussian "
+                                   "stays visible in every view",
                        "n_visible": n_visible, "duplicates_D": int(D), "visited_D_star": d_star,
                        "max_tile_list": max_len, "pixels_per_thread": 4,
                        "concurrent_views_per_rank": args.concurrent_views},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "exact_lists": exact_lists, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

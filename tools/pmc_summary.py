@@ -4,7 +4,10 @@ FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  MI355X_MICROARCH.md (
 gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e. reads exactly half the bytes of a wide
 coalesced stream, so `fetch_bytes_corrected` = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact for 16-B
 streaming stores and float atomics."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SIMDS, CUS, XCDS = 1024, 256, 8      # MI355X: 256 CUs x 4 SIMD-32, 8 XCDs (GRBM_GUI_ACTIVE is summed over them)
 
 SHORT = [("blend_bwd_quad", "blend_backward"), ("blend_fwd_quad", "blend_forward"), ("param_bwd", "param_backward"),
          ("preprocess_batch_kernel", "preprocess"), ("preprocess_kernel", "preprocess"), ("image_loss_kernel", "image_loss"), ("radix_scatter", "radix_scatter"), ("radix_hist", "radix_hist"),
@@ -48,8 +51,27 @@ def main():
             e["write_bytes"] = e["WRITE_SIZE"] * 1024
         if "fetch_bytes_corrected" in e and "write_bytes" in e:
             e["hbm_traffic_bytes"] = e["fetch_bytes_corrected"] + e["write_bytes"]
+        # issue utilisation from the counters: chip cycles of the launch = GRBM_GUI_ACTIVE / 8 (the counter is
+        # summed over the XCDs); a wave64 vector instruction occupies its SIMD-32 for 2 cycles (transcendentals,
+        # DPP, compares and lane swaps for more: a lower bound), the one scalar unit of a CU issues one SALU
+        # instruction per cycle
+        if "GRBM_GUI_ACTIVE" in e and "SQ_INSTS_VALU" in e:
+            cycles = e["GRBM_GUI_ACTIVE"] / XCDS
+            e["clock_ghz"] = round(cycles / (e["avg_duration_us_under_pmc"] * 1e3), 3)
+            e["valu_issue_frac"] = round(e["SQ_INSTS_VALU"] * 2.0 / (SIMDS * cycles), 4)
+            if "SQ_INSTS_SALU" in e:
+                e["salu_issue_frac"] = round(e["SQ_INSTS_SALU"] / (CUS * cycles), 4)
+            if "SQ_WAVE_CYCLES" in e and "SQ_WAIT_INST_ANY" in e:
+                e["wave_time_waiting_to_issue"] = round(e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"], 4)
+            if "SQ_WAVE_CYCLES" in e and "SQ_WAIT_ANY" in e:
+                e["wave_time_in_waitcnt"] = round(e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"], 4)
         res[k] = e
+    import bench
+    res["_meta"] = {"source_sha16": bench.source_sha16(), "passes": dirs,
+                    "workload": "tools/one_view.py: bench scene (1M gaussians, 1920x1080, log-scale U(1,3)), GS_VIEWS views "
+                                "fwd+bwd on ONE stream, one batched K1 and K8"}
     json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
+    res.pop("_meta")
     for k, e in sorted(res.items(), key=lambda kv: -kv[1]["avg_duration_us_under_pmc"]):
         print(f"{k:16s} {e['avg_duration_us_under_pmc']:8.1f} us  fetch(corr) {e.get('fetch_bytes_corrected', 0) / 1e6:8.1f} MB  "
               f"write {e.get('write_bytes', 0) / 1e6:8.1f} MB  atomics {e.get('TCC_EA0_ATOMIC_sum', 0) * 64 / 1e6:7.1f} MB")
