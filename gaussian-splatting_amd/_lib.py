@@ -12,7 +12,8 @@ class GsCamera(ctypes.Structure):
                 ("fx", ctypes.c_double), ("fy", ctypes.c_double),
                 ("cam_width", ctypes.c_int32), ("cam_height", ctypes.c_int32),
                 ("res_w", ctypes.c_int32), ("res_h", ctypes.c_int32),
-                ("tile_size", ctypes.c_int32), ("sh_degree", ctypes.c_int32)]
+                ("tile_size", ctypes.c_int32), ("sh_degree", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
 
 
 class GsViewBackward(ctypes.Structure):

@@ -170,7 +170,16 @@ def _np_out(t, dtype):
     return t.detach().cpu().numpy().astype(dtype)
 
 
-def make_camera(camera, camera_r, camera_t, result_size, tile_size, degrees):
+CAM_APPLY_VIEW, CAM_DIAG_SCALE = 1, 2     # gs_camera.flags (include/gsplat.h)
+
+
+def camera_flags(apply_view=False, diag_scale=False):
+    """0 is the reference's live path bit for bit; the two switches select the 'sane' variant of quirk Q1
+    (centres projected from view space) and Q4 (diagonal scale matrix).  No reference counterpart."""
+    return (CAM_APPLY_VIEW if apply_view else 0) | (CAM_DIAG_SCALE if diag_scale else 0)
+
+
+def make_camera(camera, camera_r, camera_t, result_size, tile_size, degrees, flags=0):
     c = GsCamera()
     r = np.asarray(camera_r.detach().cpu() if _is_t(camera_r) else camera_r, dtype=np.float64).reshape(3, 3)
     t = np.asarray(camera_t.detach().cpu() if _is_t(camera_t) else camera_t, dtype=np.float64).reshape(3)
@@ -185,6 +194,7 @@ def make_camera(camera, camera_r, camera_t, result_size, tile_size, degrees):
     c.res_w, c.res_h = int(result_size[0]), int(result_size[1])
     c.tile_size = int(tile_size)
     c.sh_degree = int(degrees)
+    c.flags = int(flags)
     return c
 
 
@@ -238,16 +248,17 @@ def _gaussian_tensors(g, device):
 
 # --------------------------------------------------------------------------- forward_pass
 def forward_pass(ctx, queue, program, camera, camera_r, camera_t, gaussians,
-                 result_size=[979, 546], tile_size=16, training=True):
+                 result_size=[979, 546], tile_size=16, training=True, apply_view=False, diag_scale=False):
     """forward_pass.py:25-136.  Returns the 13-tuple (training) or 6-tuple of the reference:
     centers, depths, colors, conics, [clamped,] tiles_touched, radii[, Ws, Ms, Ts, cov2d, cov3d,
-    dirs]."""
+    dirs].  apply_view / diag_scale: see camera_flags (default: the reference's behaviour)."""
     c = _ctx(ctx)
     c.sync_stream()
     dev = c.device
     numpy_mode = not _is_t(gaussians.center)
     N, means, scales, quats, sh = _gaussian_tensors(gaussians, dev)
-    cam = make_camera(camera, camera_r, camera_t, result_size, tile_size, gaussians.degrees)
+    cam = make_camera(camera, camera_r, camera_t, result_size, tile_size, gaussians.degrees,
+                      camera_flags(apply_view, diag_scale))
     f32, i32 = torch.float32, torch.int32
     centers = torch.empty((N, 2), dtype=f32, device=dev)
     depths = torch.empty((N,), dtype=i32, device=dev)
@@ -561,7 +572,8 @@ def backward_params(c, means, scales, quats, sh, cam, radii, clamped, d_centers_
 
 def backward_pass(ctx, queue, program, camera, camera_r, camera_t, gaussians,
                   radii, covs_2d, covs_3d, ws, ms, ts, dirs, clampeds,
-                  d_colors, d_2d_centers, d_conics, *, result_size=[979, 546], tile_size=16):
+                  d_colors, d_2d_centers, d_conics, *, result_size=[979, 546], tile_size=16,
+                  apply_view=False, diag_scale=False):
     """backward_pass.py:19-68 -> (d_colors, d_centers, d_shs, d_scales, d_rots).
 
     d_colors: the incoming colour gradient masked by the clamp flags (the intent of
@@ -581,7 +593,8 @@ def backward_pass(ctx, queue, program, camera, camera_r, camera_t, gaussians,
             raise ValueError(f"{name} must be [N,{tail}]")
     if ms is not None and (len(ms) != N or int(np.prod(ms.shape[1:])) != 9):
         raise ValueError("ms must be [N,3,3]")
-    cam = make_camera(camera, camera_r, camera_t, result_size, tile_size, gaussians.degrees)
+    cam = make_camera(camera, camera_r, camera_t, result_size, tile_size, gaussians.degrees,
+                      camera_flags(apply_view, diag_scale))
     rad = _dev(radii, torch.int32, dev, (N,))
     cl = _dev(clampeds, torch.uint8, dev, (N, 3))
     W, H = int(result_size[0]), int(result_size[1])

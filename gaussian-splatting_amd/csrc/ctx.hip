@@ -1,5 +1,7 @@
 // Device context: replaces setup_gpu() (setup_gpu.py:3-6,370).
 #include "common.h"
+
+static_assert(sizeof(gs_camera) == 144, "gs_camera layout is part of the C ABI (tests/test_abi.py mirrors it)");
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>

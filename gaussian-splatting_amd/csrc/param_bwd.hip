@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
     // S', M = R S' and Sigma = M M^T do not depend on the view (scale_mod is a frame constant,
     // checked on the host): once per gaussian (forward_pass.py:74-76)
     const double sm = args.v[0].cam.scale_mod;
-    const double S[9] = {sc[0] * sm, sm, sm, sm, sc[1] * sm, sm, sm, sm, sc[2] * sm};
+    const double so = args.v[0].cam.diag_scale ? 0.0 : sm;     // GS_CAM_DIAG_SCALE (the same for every view: host check)
+    const double S[9] = {sc[0] * sm, so, so, so, sc[1] * sm, so, so, so, sc[2] * sm};
     double M[9], Sg[9];
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++)
@@ -135,17 +136,25 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
         g_op += in.d_op;
         const float *in_c = in.c, *in_con = in.con, *in_col = in.col;
 
+        // ---- recompute the W rows and cov2d (forward_pass.py:78-86)
+        const double tz = cam.Rt[6] * x + cam.Rt[7] * y + cam.Rt[8] * z + cam.t[2];
+
         // ---- 2D centre <- world mean (quirk Q1: proj_mat on world coordinates)
-        {
+        if (!cam.apply_view) {
             const double dcx = in_c[0], dcy = in_c[1];
             const double mw = 1.0 / (z + .00000001);
             g_mean[0] += dcx * (.5 * cam.W * cam.p00 * mw);
             g_mean[1] += dcy * (.5 * cam.H * cam.p11 * mw);
             g_mean[2] += -dcx * (.5 * cam.W * cam.p00 * x * mw * mw) - dcy * (.5 * cam.H * cam.p11 * y * mw * mw);
+        } else {    // GS_CAM_APPLY_VIEW: the centre is projected from t = R^T p + t_cam
+            const double tx = cam.Rt[0] * x + cam.Rt[1] * y + cam.Rt[2] * z + cam.t[0];
+            const double ty = cam.Rt[3] * x + cam.Rt[4] * y + cam.Rt[5] * z + cam.t[1];
+            const double mw = 1.0 / (tz + .00000001);
+            const double d_tx = in_c[0] * (.5 * cam.W * cam.p00 * mw), d_ty = in_c[1] * (.5 * cam.H * cam.p11 * mw);
+            const double d_tzc = -(d_tx * tx + d_ty * ty) * mw;
+            for (int k = 0; k < 3; k++) g_mean[k] += d_tx * cam.Rt[k] + d_ty * cam.Rt[3 + k] + d_tzc * cam.Rt[6 + k];
         }
 
-        // ---- recompute the W rows and cov2d (forward_pass.py:78-86)
-        const double tz = cam.Rt[6] * x + cam.Rt[7] * y + cam.Rt[8] * z + cam.t[2];
         const double j00 = cam.fx / tz, j11 = cam.fy / tz;
         const double W0[3] = {j00 * cam.Rt[0], j00 * cam.Rt[1], j00 * cam.Rt[2]};
         const double W1[3] = {j11 * cam.Rt[3], j11 * cam.Rt[4], j11 * cam.Rt[5]};
@@ -382,6 +391,7 @@ extern "C" int gs_backward_params_batch(gs_ctx *ctx, int32_t N, const float *mea
         GS_REQUIRE(((uintptr_t)views[v].grad_rows & 15) == 0, "gs_backward_params_batch: grad_rows must be 16-byte aligned");
         GS_REQUIRE(views[v].cam->res_h == views[0].cam->res_h,
                    "gs_backward_params_batch: all views of a batch must share result_size (scale_mod)");
+        GS_REQUIRE(views[v].cam->flags == views[0].cam->flags, "gs_backward_params_batch: all views of a batch must share camera flags");
     }
     GS_HIP(hipSetDevice(ctx->device));
     // chunks of MAX_BATCH_VIEWS views; the first chunk writes (unless accumulate), the rest add

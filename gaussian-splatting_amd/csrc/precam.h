@@ -11,6 +11,7 @@ struct PreCam {
     double fx, fy;
     double scale_mod;      // 3 / result_size[1]    (forward_pass.py:50)
     int W, H, tile, degree;
+    int apply_view, diag_scale;   // gs_camera.flags (0, 0 = strict reference)
 };
 
 // forward_pass.py:8-21

@@ -42,15 +42,19 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
     }
 
     do {
-        // :59-61  clip-space centre from WORLD coordinates (quirk Q1)
-        const double mod_w = 1.0 / (z + .00000001);
-        const double ndc_x = (cam.p00 * x) * mod_w;
-        const double ndc_y = (cam.p11 * y) * mod_w;
-
-        // :64-67  view-space position, near cull at z <= 2 (quirk Q6)
+        // :64  view-space position
         const double tx = ((cam.Rt[0] * x + cam.Rt[1] * y) + cam.Rt[2] * z) + cam.t[0];
         const double ty = ((cam.Rt[3] * x + cam.Rt[4] * y) + cam.Rt[5] * z) + cam.t[1];
         const double tz = ((cam.Rt[6] * x + cam.Rt[7] * y) + cam.Rt[8] * z) + cam.t[2];
+
+        // :59-61  clip-space centre from WORLD coordinates (quirk Q1); GS_CAM_APPLY_VIEW: from the view-space
+        // position (the line the reference has commented out, :57)
+        const double hx = cam.apply_view ? tx : x, hy = cam.apply_view ? ty : y, hz = cam.apply_view ? tz : z;
+        const double mod_w = 1.0 / (hz + .00000001);
+        const double ndc_x = (cam.p00 * hx) * mod_w;
+        const double ndc_y = (cam.p11 * hy) * mod_w;
+
+        // :65-67  near cull at z <= 2 (quirk Q6)
         if (tz <= 2.0 || isnan(tz)) break;
 
         // :70-71  depth key = int(z*1000) wrapped to int32 (quirk Q7)
@@ -75,9 +79,10 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
 
         // :75  M = R @ ([[s0,1,1],[1,s1,1],[1,1,s2]] * scale_mod) (quirk Q4)
         const double sm = cam.scale_mod;
-        const double S[9] = {exp((double)ls[0]) * sm, sm, sm,
-                             sm, exp((double)ls[1]) * sm, sm,
-                             sm, sm, exp((double)ls[2]) * sm};
+        const double so = cam.diag_scale ? 0.0 : sm;       // off-diagonals: 1 * scale_mod in the reference
+        const double S[9] = {exp((double)ls[0]) * sm, so, so,
+                             so, exp((double)ls[1]) * sm, so,
+                             so, so, exp((double)ls[2]) * sm};
         double M[9];
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -307,6 +312,8 @@ int gs_make_precam(const gs_camera *cam, PreCam *out) {
     pc.fy = cam->fy;
     pc.scale_mod = (1.0 / cam->res_h) * 3;
     pc.W = cam->res_w; pc.H = cam->res_h; pc.tile = cam->tile_size; pc.degree = cam->sh_degree;
+    pc.apply_view = (cam->flags & GS_CAM_APPLY_VIEW) ? 1 : 0;
+    pc.diag_scale = (cam->flags & GS_CAM_DIAG_SCALE) ? 1 : 0;
     return GS_OK;
 }
 

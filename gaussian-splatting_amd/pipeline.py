@@ -77,8 +77,9 @@ class SplatPipeline:
     """Holds the parameters on one device and runs views through the native kernels."""
 
     def __init__(self, gaussians, result_size, tile_size=16, background=(0., 0., 0.), pixel_offset=0.5,
-                 opacity_is_logit=True, ctx=None, cull_tiles=True):
+                 opacity_is_logit=True, ctx=None, cull_tiles=True, apply_view=False, diag_scale=False):
         self.ctx = api._ctx(ctx)
+        self.cam_flags = api.camera_flags(apply_view, diag_scale)   # 0 = the reference's quirks Q1/Q4 kept
         self.cull_tiles = bool(cull_tiles)   # gs_bin_*_culled: same images/gradients, about half the list
         dev = self.ctx.device
         self.N, self.means, self.log_scales, self.quats, self.sh = api._gaussian_tensors(gaussians, dev)
@@ -136,7 +137,8 @@ class SplatPipeline:
         c.sync_stream()
         records = self.cull_tiles if records is None else bool(records)
         opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity   # once for the batch
-        cams = [api.make_camera(v.camera, v.camera_r, v.camera_t, self.result_size, self.tile_size, self.degrees)
+        cams = [api.make_camera(v.camera, v.camera_r, v.camera_t, self.result_size, self.tile_size, self.degrees,
+                                 self.cam_flags)
                 for v in views]
         if records:
             dev, N, i32 = self.ctx.device, self.N, torch.int32
@@ -180,7 +182,7 @@ class SplatPipeline:
         N = self.N
         if pre is None:
             pre = self._alloc_pre(api.make_camera(view.camera, view.camera_r, view.camera_t, self.result_size,
-                                                  self.tile_size, self.degrees))
+                                                  self.tile_size, self.degrees, self.cam_flags))
             null = ctypes.c_void_p(0)
             check(c.lib.gs_preprocess(c.handle, N, api._ptr(self.means), api._ptr(self.log_scales),
                                       api._ptr(self.quats), api._ptr(self.sh), ctypes.byref(pre["cam"]),

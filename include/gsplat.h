@@ -35,7 +35,17 @@ typedef struct gs_camera {
     int32_t res_w, res_h; /* result_size                                                      */
     int32_t tile_size;    /* 16                                                               */
     int32_t sh_degree;    /* gaussians.degrees, 0..3                                          */
+    int32_t flags;        /* 0 = the reference's live forward path, bit for bit (strict).  "Sane"
+                           * variants of two of its quirks, as constant branches of the same kernels
+                           * (no reference counterpart; K8 differentiates whichever is selected):
+                           * GS_CAM_APPLY_VIEW  the 2D centre is projected from VIEW-space coordinates
+                           *   (the reference projects world coordinates: forward_pass.py:57 is
+                           *   commented out, :59-61 use the world position);
+                           * GS_CAM_DIAG_SCALE  the scale matrix is diag(s) * scale_mod (the reference
+                           *   fills the off-diagonals with 1, forward_pass.py:75). */
 } gs_camera;
+#define GS_CAM_APPLY_VIEW 1
+#define GS_CAM_DIAG_SCALE 2
 
 /* Replaces setup_gpu() (setup_gpu.py:3-6,370): device context = device id + stream + workspace
  * arena. `stream` is a hipStream_t (NULL = default stream). */

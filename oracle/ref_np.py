@@ -119,8 +119,13 @@ def _py_clamp_to_tiles(v, size, tile):
 
 
 def preprocess(means, log_scales, quats, sh, degree, fx, fy, cam_width, cam_height,
-               camera_r, camera_t, result_size=(979, 546), tile_size=16):
+               camera_r, camera_t, result_size=(979, 546), tile_size=16, apply_view=False, diag_scale=False):
     """forward_pass.py:25-136 (training=True outputs), vectorised.
+
+    apply_view / diag_scale (default False = the reference): the library's GS_CAM_APPLY_VIEW /
+    GS_CAM_DIAG_SCALE variants -- project the VIEW-space position (the line the reference has commented
+    out, forward_pass.py:57) / zero the off-diagonals of S.  These two have no reference output to pin
+    them: "parity unpinned", checked only oracle-vs-library.
 
     means[N,3], log_scales[N,3], quats[N,4] (w,x,y,z), sh[N,3,16]; camera_r[3,3], camera_t[3].
     Returns a dict with the 13 reference outputs (same names as forward_pass.py:134 locals,
@@ -153,11 +158,15 @@ def preprocess(means, log_scales, quats, sh, degree, fx, fy, cam_width, cam_heig
         return out
 
     orig = np.concatenate([means, np.ones((N, 1))], axis=1)
-    pc = orig @ proj.T                                           # :59
     with np.errstate(all='ignore'):
+        vc = orig @ view.T                                       # :64
+        if apply_view:
+            vh = np.concatenate([vc[:, :3], np.ones((N, 1))], axis=1)
+            pc = vh @ proj.T                                     # :57 (commented out in the reference)
+        else:
+            pc = orig @ proj.T                                   # :59
         mod_w = 1.0 / (pc[:, 3] + .00000001)                     # :60
         center_ndc = pc * mod_w[:, None]                         # :61
-        vc = orig @ view.T                                       # :64
         zv = vc[:, 2]
         alive = ~((zv <= 2) | np.isnan(zv))                      # :65-67
 
@@ -170,7 +179,7 @@ def preprocess(means, log_scales, quats, sh, degree, fx, fy, cam_width, cam_heig
 
         qn = quats / np.linalg.norm(quats, axis=1, keepdims=True)   # :74
         R = quat_to_rotmat(qn)
-        S = np.ones((N, 3, 3))
+        S = np.zeros((N, 3, 3)) if diag_scale else np.ones((N, 3, 3))
         S[:, 0, 0], S[:, 1, 1], S[:, 2, 2] = scales[:, 0], scales[:, 1], scales[:, 2]
         S = S * scale_mod                                        # :75 (off-diagonals are 1: quirk Q4)
         M = R @ S

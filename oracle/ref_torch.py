@@ -53,7 +53,7 @@ def sh_basis(d, degree):
 
 
 def preprocess(means, log_scales, quats, sh, degree, fx, fy, cam_width, cam_height,
-               camera_r, camera_t, result_size):
+               camera_r, camera_t, result_size, apply_view=False, diag_scale=False):
     """Differentiable part of forward_pass.py:56-127: centers[N,2] (pixels), conics[N,3],
     colors[N,3] for every gaussian (no culling -- the caller masks with the discrete outputs of
     ref_np.preprocess)."""
@@ -67,19 +67,21 @@ def preprocess(means, log_scales, quats, sh, degree, fx, fy, cam_width, cam_heig
     scale_mod = (1.0 / H) * 3
     N = means.shape[0]
 
-    # 2D centre straight from world coordinates (quirk Q1, forward_pass.py:58-61,114)
-    mod_w = 1.0 / (means[:, 2] * proj[3, 2] + .00000001)
-    ndc_x = means[:, 0] * proj[0, 0] * mod_w
-    ndc_y = means[:, 1] * proj[1, 1] * mod_w
+    tview = means @ R_c + t_c                      # rows of (R^T p + t)
+    # 2D centre straight from world coordinates (quirk Q1, forward_pass.py:58-61,114); apply_view: from tview
+    hom = tview if apply_view else means
+    mod_w = 1.0 / (hom[:, 2] * proj[3, 2] + .00000001)
+    ndc_x = hom[:, 0] * proj[0, 0] * mod_w
+    ndc_y = hom[:, 1] * proj[1, 1] * mod_w
     cx = ((ndc_x + 1.0) * W - 1.0) * .5
     cy = ((ndc_y + 1.0) * H - 1.0) * .5
 
-    tview = means @ R_c + t_c                      # rows of (R^T p + t)
     qn = quats / quats.norm(dim=1, keepdim=True)
     R = quat_to_rotmat(qn)
     s = torch.exp(log_scales)
-    S = torch.ones(N, 3, 3, dtype=torch.float64)
-    S = S - torch.diag_embed(torch.ones(N, 3, dtype=torch.float64)) + torch.diag_embed(s)
+    S = torch.diag_embed(s)
+    if not diag_scale:
+        S = S + torch.ones(N, 3, 3, dtype=torch.float64) - torch.diag_embed(torch.ones(N, 3, dtype=torch.float64))
     S = S * scale_mod
     M = R @ S
     cov3 = M @ M.transpose(1, 2)
@@ -152,16 +154,19 @@ def blend(centers, colors, opacities, conics, vals, ranges, result_size, tile_si
 
 
 def render(means, log_scales, quats, sh, opacities, degree, fx, fy, cam_width, cam_height,
-           camera_r, camera_t, result_size, tile_size=16, background=(0, 0, 0), pixel_offset=0.5):
+           camera_r, camera_t, result_size, tile_size=16, background=(0, 0, 0), pixel_offset=0.5,
+           apply_view=False, diag_scale=False):
     """Full differentiable forward: discrete decisions from ref_np.preprocess / bin_duplicates on
     the detached parameters, continuous values from the torch graph."""
     disc = ref_np.preprocess(means.detach().numpy(), log_scales.detach().numpy(),
                              quats.detach().numpy(), sh.detach().numpy(), degree, fx, fy,
-                             cam_width, cam_height, camera_r, camera_t, result_size, tile_size)
+                             cam_width, cam_height, camera_r, camera_t, result_size, tile_size,
+                             apply_view=apply_view, diag_scale=diag_scale)
     keys, vals, ranges = ref_np.bin_duplicates(disc['tiles_touched'], disc['depths'], result_size,
                                                tile_size)
     centers, conics, colors = preprocess(means, log_scales, quats, sh, degree, fx, fy, cam_width,
-                                         cam_height, camera_r, camera_t, result_size)
+                                         cam_height, camera_r, camera_t, result_size, apply_view=apply_view,
+                                         diag_scale=diag_scale)
     vis = torch.as_tensor(disc['radii'] > 0)
     # culled gaussians keep zero centre/colour (forward_pass.py:122-127); they own no tiles
     centers = torch.where(vis[:, None], centers, torch.zeros_like(centers))

@@ -41,7 +41,7 @@ def test_argument_errors_are_reported_without_a_gpu():
 def test_camera_struct_layout_matches_header():
     from importlib import import_module
     lib = import_module("gaussian-splatting_amd._lib")
-    assert ctypes.sizeof(lib.GsCamera) == 9 * 8 + 3 * 8 + 2 * 8 + 6 * 4
+    assert ctypes.sizeof(lib.GsCamera) == 9 * 8 + 3 * 8 + 2 * 8 + 7 * 4 + 4      # 7 int32 + tail padding to 8
 
 
 def test_product_path_refuses_to_run_without_gpu():

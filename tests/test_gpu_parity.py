@@ -200,14 +200,14 @@ def test_blend_empty_and_background_only(gpu_ctx):
 
 
 # ------------------------------------------------------------------ K7 + K8 backward
-def _autograd_reference(d, wimg, offset):
+def _autograd_reference(d, wimg, offset, **modes):
     import torch
     p = {k: torch.tensor(np.asarray(d[k], dtype=np.float32).astype(np.float64), requires_grad=True)
          for k in ("in_center", "in_scaling", "in_rotation", "in_sh", "in_opacity")}
     img, aux = ref_torch.render(p["in_center"], p["in_scaling"], p["in_rotation"], p["in_sh"], p["in_opacity"],
                                 int(d["in_degrees"]), float(d["in_fx"]), float(d["in_fy"]), int(d["in_cam_w"]),
                                 int(d["in_cam_h"]), d["in_R"], d["in_t"], d["in_result_size"].tolist(), 16,
-                                d["in_bg"], offset)
+                                d["in_bg"], offset, **modes)
     for k in ("centers", "conics", "colors"):
         aux[k].retain_grad()
     (img * torch.tensor(wimg, dtype=torch.float64)).sum().backward()
@@ -261,6 +261,74 @@ def test_gradients_vs_fp64_autograd(gpu_ctx, name, ppt):
         assert np.all(dc[clamped > 0] == 0)
     finally:
         gpu_ctx.set_option("pixels_per_thread", 4)
+
+
+@pytest.mark.parametrize("name", ["s3", "dense"])
+@pytest.mark.parametrize("apply_view,diag_scale", [(True, False), (False, True), (True, True)])
+def test_sane_mode_switches_vs_oracles(gpu_ctx, name, apply_view, diag_scale):
+    """gs_camera.flags: GS_CAM_APPLY_VIEW (quirk Q1 off) and GS_CAM_DIAG_SCALE (quirk Q4 off) as constant
+    branches of K1 and K8.  Neither variant exists in the reference ("parity unpinned"): the bar is the
+    oracle with the same switch -- discrete outputs bit-exact, floats as stored fp32, image 1e-4 away from
+    fragile pixels, gradients 1e-4 against float64 autograd."""
+    import gsplat_amd as gs
+    if name == "dense":        # the synthetic scene's camera is the identity: turn and shift it so that Q1 matters
+        cam_, _, _, g_, rs_ = dense_scene()
+        d = as_record(cam_, [[0.9950, 0.0, 0.0998], [0.0, 1.0, 0.0], [-0.0998, 0.0, 0.9950]], [0.3, -0.2, 0.4], g_, rs_,
+                      bg=(.2, .1, .3))
+    else:
+        d = load_scene(name)
+    cam, R, t, g, rs, bg = scene_inputs(d)
+    modes = dict(apply_view=apply_view, diag_scale=diag_scale)
+    out = gs.forward_pass(gpu_ctx, None, None, cam, R, t, g, result_size=rs, tile_size=16, training=True, **modes)
+    (centers, depths, colors, conics, clamped, tiles_touched, radii, Ws, Ms, Ts, cov2d, cov3d, dirs) = out
+    o = ref_np.preprocess(g.center, g.scaling, g.rotation, g.spherical_harmonics, int(d["in_degrees"]), cam.params[0],
+                          cam.params[1], cam.width, cam.height, R, t, rs, 16, **modes)
+    strict = ref_np.preprocess(g.center, g.scaling, g.rotation, g.spherical_harmonics, int(d["in_degrees"]),
+                               cam.params[0], cam.params[1], cam.width, cam.height, R, t, rs, 16)
+    assert not (np.array_equal(o["centers"], strict["centers"]) and np.array_equal(o["conics"], strict["conics"])), \
+        "the switch must change something on this scene"
+    for n, v in (("depths", depths), ("tiles_touched", tiles_touched), ("radii", radii), ("clamped", clamped)):
+        assert np.array_equal(v, o[n].astype(v.dtype)), n
+    assert (radii > 0).sum() >= 10
+    np.testing.assert_allclose(centers, o["centers"], rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(conics, o["conics"], rtol=4e-6, atol=1e-7)
+    np.testing.assert_allclose(colors, o["colors"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(Ms.reshape(len(radii), 9), o["Ms"].reshape(len(radii), 9), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(cov3d, o["cov3d"], rtol=2e-6, atol=1e-12)
+
+    rng = np.random.default_rng(11)
+    wimg = rng.normal(size=(rs[0], rs[1], 3)).astype(np.float32)
+    b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tiles_touched, radii, depths, result_size=rs)
+    # fragile pixels (within 1e-4 of a skip/break threshold in fp64) carry no weight: see _check_image
+    ref_img, _, _, fragile, _ = cref.rasterize_frame(centers, colors, np.asarray(g.opacity, dtype=np.float32), conics,
+                                                     b.vals.cpu().numpy(), b.ranges.cpu().numpy(), rs, bg, pixel_offset=0.5,
+                                                     margin=1e-4)
+    wimg = wimg * (~fragile.astype(bool))[:, :, None]
+    image, d_colors, d_centers, d_conics, d_opac = gs.gpu_rasterize(
+        gpu_ctx, None, None, centers, colors, g.opacity, conics, b, training=True, result_size=rs,
+        background_color=bg, dL_dimage=wimg, pixel_offset=0.5)
+    _check_image(image, ref_img, fragile, f"{name} {modes}", max_fragile=2e-2)
+    p, aux = _autograd_reference(d, wimg, 0.5, **modes)
+    dc, d_means, d_shs, d_scales, d_rots = gs.backward_pass(
+        gpu_ctx, None, None, cam, R, t, g, radii, cov2d, cov3d, Ws, Ms, Ts, dirs, clamped, d_colors,
+        d_centers, d_conics, result_size=rs, **modes)
+    _assert_grad(d_means, p["in_center"].grad.numpy(), "d_means")
+    _assert_grad(d_scales, p["in_scaling"].grad.numpy(), "d_scales")
+    _assert_grad(d_rots, p["in_rotation"].grad.numpy(), "d_rots")
+    _assert_grad(d_shs, p["in_sh"].grad.numpy().transpose(0, 2, 1), "d_shs")
+    _assert_grad(d_opac, p["in_opacity"].grad.numpy(), "d_opacity")
+
+    # the pipeline takes the same switches and gives the same gradients
+    gpu = gs.GaussianSet(*[np.asarray(x) for x in (g.center, g.spherical_harmonics, g.scaling, g.rotation, g.opacity)],
+                         degrees=int(d["in_degrees"]))
+    pipe = gs.SplatPipeline(gpu, rs, background=bg, opacity_is_logit=False, ctx=gpu_ctx, **modes)
+    grads = gs.FlatGrads(len(radii), gpu_ctx.device)
+    import torch
+    img2, st = pipe.forward(gs.View(cam, R, t))
+    pipe.backward(st, torch.as_tensor(wimg, device=gpu_ctx.device), grads)
+    np.testing.assert_allclose(img2.cpu().numpy(), image, rtol=0, atol=2e-6)
+    _assert_grad(grads.means.cpu().numpy(), p["in_center"].grad.numpy(), "pipeline d_means")
+    _assert_grad(grads.log_scales.cpu().numpy(), p["in_scaling"].grad.numpy(), "pipeline d_scales")
 
 
 def test_default_dl_dimage_is_the_rendered_image(gpu_ctx):

@@ -146,3 +146,43 @@ def test_torch_oracle_gradient_against_finite_differences():
         fd = (up - dn) / (2 * h)
         an = p[key].grad[idx].item()
         assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)), (key, idx, fd, an)
+
+
+@pytest.mark.parametrize("apply_view,diag_scale", [(True, False), (False, True), (True, True)])
+def test_sane_mode_oracles_agree_with_each_other(apply_view, diag_scale):
+    """The apply_view / diag_scale variants (no reference counterpart: "parity unpinned") -- the numpy and
+    the torch restatement agree on the continuous outputs, the defaults still give the golden values, and
+    autograd through the variant matches central differences."""
+    import torch
+    d = load_scene("s1")
+    rs = d["in_result_size"].tolist()
+    args = (int(d["in_degrees"]), float(d["in_fx"]), float(d["in_fy"]), int(d["in_cam_w"]), int(d["in_cam_h"]),
+            d["in_R"], d["in_t"], rs)
+    modes = dict(apply_view=apply_view, diag_scale=diag_scale)
+    o = ref_np.preprocess(d["in_center"], d["in_scaling"], d["in_rotation"], d["in_sh"], *args, 16, **modes)
+    T = lambda k: torch.tensor(d[k], dtype=torch.float64)
+    c, con, col = ref_torch.preprocess(T("in_center"), T("in_scaling"), T("in_rotation"), T("in_sh"), *args, **modes)
+    vis = o["radii"] > 0
+    assert vis.sum() >= 10
+    np.testing.assert_allclose(c.numpy()[vis], o["centers"][vis], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(con.numpy()[vis], o["conics"][vis], rtol=1e-9, atol=1e-12)
+    changed = (not np.allclose(o["centers"], d["fp_centers"])) or (not np.allclose(o["conics"], d["fp_conics"]))
+    assert changed
+    if diag_scale:
+        M = o["Ms"][vis]
+        S2 = np.einsum("nij,nik->njk", M, M)              # S^T R^T R S = S^2: diagonal
+        off = S2 - np.einsum("nii->ni", S2)[:, :, None] * np.eye(3)
+        assert np.abs(off).max() < 1e-12
+
+    p = T("in_center").clone().requires_grad_(True)
+    w = torch.tensor(np.random.default_rng(2).normal(size=(int(vis.sum()), 2)))
+    f = lambda x: (ref_torch.preprocess(x, T("in_scaling"), T("in_rotation"), T("in_sh"), *args, **modes)[0][vis] * w).sum()
+    f(p).backward()
+    i = int(np.nonzero(vis)[0][3])
+    for k in range(3):
+        q = T("in_center").clone()
+        q[i, k] += 1e-6
+        up = f(q).item()
+        q[i, k] -= 2e-6
+        fd = (up - f(q).item()) / 2e-6
+        assert abs(fd - p.grad[i, k].item()) <= 1e-5 * max(1.0, abs(fd))
