@@ -55,15 +55,28 @@ __device__ inline uint32_t tile_count(const int4 r, int depth, Grid g, int &x0, 
     return depth == 0 ? 0u : (uint32_t)w * (uint32_t)h;
 }
 
+// Wave64 inclusive scans on the DPP crossbar: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then the last lane of
+// row 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31).  Lanes without a source
+// take the identity.  Six VALU steps; a __shfl_up ladder is six dependent trips through the LDS crossbar.
+#define GS_DPP_SCAN(OP, IDENT)                                                                        \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x111, 0xf, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x112, 0xf, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x114, 0xf, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x118, 0xf, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x142, 0xa, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x143, 0xc, 0xf, false));
+__device__ __forceinline__ uint32_t gs_add_u32(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t gs_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    GS_DPP_SCAN(gs_add_u32, 0u)
     return v;
 }
+// running maximum (identity 0)
+__device__ inline uint32_t wave_inclusive_max(uint32_t v) {
+    GS_DPP_SCAN(gs_max_u32, 0u)
+    return v;
+}
+#undef GS_DPP_SCAN
 
 // block-wide exclusive scan of one value per thread (256 threads = 4 waves); returns the
 // exclusive prefix, *block_total gets the sum
@@ -206,16 +219,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void sorted_offsets_kernel(int N, con
     }
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The 64 lanes of a wave hold runs of `cnt` consecutive output slots starting at `first` (its exclusive prefix).
+// Returns, for slot sbase + lane of the concatenation, the lane that owns it: every lane whose run starts inside
+// the window [sbase, sbase + 64) marks its first slot in the wave's LDS row, and a running maximum carries the
+// owner over the rest of its run (owners grow with the slot); slots before the window's first mark belong to the
+// run that was open at the end of the previous window (`carry`, wave-uniform, 0 at the start).  One LDS round
+// trip and six DPP steps per window -- a binary search over the prefix array is six dependent LDS reads, and the
+// kernels that walk rects are bound by exactly that latency.  LDS operations of one wave execute in order.
+__device__ __forceinline__ uint32_t slot_owner(uint32_t *mark_row, int lane, uint32_t cnt, uint32_t first,
+                                               uint32_t sbase, uint32_t &carry) {
+    mark_row[lane] = 0u;
+    wave_lds_sync();
+    if (cnt != 0u && first >= sbase && first < sbase + 64u) mark_row[first - sbase] = (uint32_t)lane + 1u;
+    wave_lds_sync();
+    uint32_t m = wave_inclusive_max(mark_row[lane]);
+    m = max(m, carry);
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+    wave_lds_sync();                  // the row is rewritten by the next window
+    return m - 1u;                    // a slot below the wave's total always has an owner (m >= 1)
+}
+
 // K3: duplicate.  One wave per 64 consecutive positions of the depth order; the wave's output
-// slots are a contiguous range, filled cooperatively so stores are coalesced and a gaussian
-// covering hundreds of tiles does not serialise its wave.
+// slots are a contiguous range, filled cooperatively (64 slots per step, slot_owner) so stores are
+// coalesced and a gaussian covering hundreds of tiles does not serialise its wave.
 __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__restrict__ perm,
                                                         const int4 *__restrict__ rect,
                                                         const int32_t *__restrict__ depth, Grid grid,
                                                         const uint32_t *__restrict__ offsets,
                                                         uint32_t *__restrict__ tile_keys, int32_t *__restrict__ vals) {
-    __shared__ uint32_t s_pref[4][64];   // inclusive prefix of counts within the wave
+    __shared__ uint32_t s_first[4][64];  // exclusive prefix of counts within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
+    __shared__ uint32_t s_mark[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = (blockIdx.x * 4 + wave) * 64;
     const int i = i0 + lane;
@@ -226,25 +266,23 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
         cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
     }
     const uint32_t inc = wave_inclusive_scan(cnt);
-    s_pref[wave][lane] = inc;
+    const uint32_t first = inc - cnt;
+    s_first[wave][lane] = first;
     s_info[wave][lane] = make_int4(x0, y0, h, g);
     const uint32_t wave_total = __shfl(inc, 63, 64);   // 0 when the whole wave is past N
     const uint32_t out_base = i0 < N ? offsets[i0] : 0u;
-    __syncthreads();
-    for (uint32_t sidx = lane; sidx < wave_total; sidx += 64) {
-        // owner = first lane whose inclusive prefix exceeds sidx (binary search, 6 steps)
-        int lo = 0, hi = 63;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pref[wave][mid] > sidx) hi = mid; else lo = mid + 1;
+    uint32_t carry = 0;
+    for (uint32_t sbase = 0; sbase < wave_total; sbase += 64) {      // wave-uniform trip count
+        const int lo = (int)slot_owner(s_mark[wave], lane, cnt, first, sbase, carry);
+        const uint32_t sidx = sbase + lane;
+        if (sidx < wave_total) {
+            const int4 inf = s_info[wave][lo];
+            const uint32_t local = sidx - s_first[wave][lo];
+            const int tx = inf.x + (int)(local / (uint32_t)inf.z);
+            const int ty = inf.y + (int)(local % (uint32_t)inf.z);
+            tile_keys[out_base + sidx] = (uint32_t)(tx * grid.tiles_y + ty);
+            vals[out_base + sidx] = inf.w;
         }
-        const int4 inf = s_info[wave][lo];
-        const uint32_t first = lo ? s_pref[wave][lo - 1] : 0u;
-        const uint32_t local = sidx - first;
-        const int tx = inf.x + (int)(local / (uint32_t)inf.z);
-        const int ty = inf.y + (int)(local % (uint32_t)inf.z);
-        tile_keys[out_base + sidx] = (uint32_t)(tx * grid.tiles_y + ty);
-        vals[out_base + sidx] = inf.w;
     }
 }
 
@@ -264,7 +302,7 @@ __device__ __forceinline__ bool pair_may_contribute(const float4 geo, const floa
 }
 
 // One wave per 64 consecutive gaussians; the wave walks the concatenation of their rects 64 pairs at a
-// time (binary search for the owner, as K3 does), so a gaussian covering thousands of tiles does not
+// time (slot_owner finds each pair's gaussian, as in K3), so a gaussian covering thousands of tiles does not
 // serialise its wave.  CULL_EMIT = false: counts[g] <- pairs that pass.  CULL_EMIT = true (gaussians taken
 // in depth order through perm): the passing pairs are written from offsets[first position of the wave]
 // on, compacted with a ballot, i.e. in (depth order, tile order).
@@ -277,10 +315,11 @@ __global__ __launch_bounds__(256) void culled_pairs_kernel(int N, const int32_t 
                                                            const uint32_t *__restrict__ offsets, uint32_t D,
                                                            uint32_t *__restrict__ tile_keys,
                                                            int32_t *__restrict__ vals) {
-    __shared__ uint32_t s_pref[4][64];   // inclusive prefix of rect sizes within the wave
+    __shared__ uint32_t s_first[4][64];  // exclusive prefix of rect sizes within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
     __shared__ float4 s_geo[4][64], s_con[4][64];
     __shared__ uint32_t s_pass[4][64];
+    __shared__ uint32_t s_mark[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = (blockIdx.x * 4 + wave) * 64;
     const int i = i0 + lane;
@@ -296,26 +335,23 @@ __global__ __launch_bounds__(256) void culled_pairs_kernel(int N, const int32_t 
         }
     }
     const uint32_t inc = wave_inclusive_scan(cnt);
-    s_pref[wave][lane] = inc;
+    const uint32_t first = inc - cnt;
+    s_first[wave][lane] = first;
     s_info[wave][lane] = make_int4(x0, y0, h, g);
     s_geo[wave][lane] = geo;
     s_con[wave][lane] = con;
     s_pass[wave][lane] = 0u;
     const uint32_t wave_total = __shfl(inc, 63, 64);   // 0 when the whole wave is past N
     uint32_t out = (CULL_EMIT && i0 < N) ? offsets[i0] : 0u;
-    __syncthreads();
+    uint32_t carry = 0;
     for (uint32_t sbase = 0; sbase < wave_total; sbase += 64) {      // wave-uniform trip count
         const uint32_t sidx = sbase + lane;
+        const int lo = (int)slot_owner(s_mark[wave], lane, cnt, first, sbase, carry);
         bool pass = false;
-        int lo = 0, tx = 0, ty = 0;
+        int tx = 0, ty = 0;
         if (sidx < wave_total) {
-            int hi = 63;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_pref[wave][mid] > sidx) hi = mid; else lo = mid + 1;
-            }
             const int4 inf = s_info[wave][lo];
-            const uint32_t local = sidx - (lo ? s_pref[wave][lo - 1] : 0u);
+            const uint32_t local = sidx - s_first[wave][lo];
             tx = inf.x + (int)(local / (uint32_t)inf.z);
             ty = inf.y + (int)(local % (uint32_t)inf.z);
             pass = pair_may_contribute(s_geo[wave][lo], s_con[wave][lo], tx, ty, cb);
