@@ -16,6 +16,11 @@ class GsCamera(ctypes.Structure):
                 ("flags", ctypes.c_int32)]
 
 
+class GsViewBin(ctypes.Structure):
+    _fields_ = [("tiles_touched", ctypes.c_void_p), ("depths", ctypes.c_void_p), ("records", ctypes.c_void_p),
+                ("vals", ctypes.c_void_p), ("ranges", ctypes.c_void_p), ("D_dev", ctypes.c_void_p)]
+
+
 class GsViewBackward(ctypes.Structure):
     _fields_ = [("cam", ctypes.POINTER(GsCamera)), ("radii", ctypes.c_void_p), ("clamped", ctypes.c_void_p),
                 ("grad_rows", ctypes.c_void_p)]
@@ -70,6 +75,9 @@ SIGNATURES = {
                                            ctypes.POINTER(_I64)]),
     "gs_bin_count_culled_begin": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float]),
     "gs_bin_count_end": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
+    "gs_bin_bounds_batch": (ctypes.c_int, [_P, _I32, _I32, ctypes.POINTER(GsViewBin), _I32, _I32, _I32, ctypes.POINTER(_I64)]),
+    "gs_bin_culled_batch": (ctypes.c_int, [_P, _I32, _I32, ctypes.POINTER(GsViewBin), _I32, _I32, _I32, ctypes.c_float, _I32,
+                                           _I64]),
     "gs_bin_fill_culled": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float, _I64,
                                           _P, _P, _P]),
     "gs_blend_forward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),

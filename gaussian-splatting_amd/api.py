@@ -394,6 +394,68 @@ def bin_culled_finish(tok, want_keys=False):
     return TileBinning(keys[:D.value] if want_keys else None, vals[:D.value], ranges, D.value, [W, H], ts)
 
 
+class DeviceTileBinning(TileBinning):
+    """Lists whose length never left the device (gs_bin_culled_batch): `vals` has the capacity the lists were
+    built with, `D_dev` = (pairs in the list, pairs found) on the device.  `.D` handed to the blend calls is the
+    capacity (ranges bound every read); true_D() copies the real length to the host (one synchronisation)."""
+
+    def __init__(self, vals, ranges, D_dev, capacity, result_size, tile_size):
+        super().__init__(None, vals, ranges, int(capacity), result_size, tile_size)
+        self.D_dev = D_dev
+
+    def true_D(self):
+        kept, found = (int(v) for v in self.D_dev.tolist())
+        if found > kept:
+            raise GsError(f"gs_bin_culled_batch: {found} pairs found, capacity {kept}: the list was truncated")
+        return kept
+
+
+def bin_bounds_batch(ctx, pres, result_size, tile_size):
+    """Per view of `pres` (records of preprocess_batch): (rect pairs, largest depth key), with one host wait."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    views = (_lib.GsViewBin * max(len(pres), 1))()
+    for k, p in enumerate(pres):
+        views[k].tiles_touched = p["rect"].data_ptr()
+        views[k].depths = p["depths"].data_ptr()
+    out = (ctypes.c_int64 * (2 * max(len(pres), 1)))()
+    N = len(pres[0]["depths"]) if pres else 0
+    check(c.lib.gs_bin_bounds_batch(c.handle, N, len(pres), views, int(result_size[0]), int(result_size[1]),
+                                    int(tile_size), out), "gs_bin_bounds_batch")
+    return [(int(out[2 * k]), int(out[2 * k + 1])) for k in range(len(pres))]
+
+
+def bin_culled_batch(ctx, pres, result_size, tile_size, pixel_offset, depth_bits=32, capacity=None):
+    """The culled lists of every view in `pres` (each with "rect", "depths" and the 64-byte records "rec") in
+    one batch of launches and no host wait; returns one DeviceTileBinning per view.  capacity: size of every
+    view's vals (default: the largest rect-pair count of the batch, from bin_bounds_batch -- one host wait)."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    dev = c.device
+    W, H, ts = int(result_size[0]), int(result_size[1]), int(tile_size)
+    if capacity is None:
+        bounds = bin_bounds_batch(c, pres, result_size, tile_size)
+        capacity = max([b[0] for b in bounds] + [1])
+        depth_bits = max(max(b[1] for b in bounds).bit_length(), 1)
+    tiles = math.ceil(W / ts) * math.ceil(H / ts)
+    N = len(pres[0]["depths"])
+    n = len(pres)
+    vals = torch.empty((n, max(int(capacity), 1)), dtype=torch.int32, device=dev)
+    ranges = torch.empty((n, tiles, 2), dtype=torch.int32, device=dev)
+    D_dev = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    views = (_lib.GsViewBin * n)()
+    for k, p in enumerate(pres):
+        views[k].tiles_touched = p["rect"].data_ptr()
+        views[k].depths = p["depths"].data_ptr()
+        views[k].records = p["rec"].data_ptr()
+        views[k].vals = vals[k].data_ptr()
+        views[k].ranges = ranges[k].data_ptr()
+        views[k].D_dev = D_dev[k].data_ptr()
+    check(c.lib.gs_bin_culled_batch(c.handle, N, n, views, W, H, ts, float(pixel_offset), int(depth_bits),
+                                    int(capacity)), "gs_bin_culled_batch")
+    return [DeviceTileBinning(vals[k], ranges[k], D_dev[k], capacity, [W, H], ts) for k in range(n)]
+
+
 def _binning_from_lists(mapped_keys, result_size, tile_size, device):
     """Accept the dict format the reference's c_rasterize/rasterize expect
     (mapped_keys[i][j] = {depth: gaussian}, rasterization.py:132,167)."""

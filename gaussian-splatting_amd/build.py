@@ -15,6 +15,7 @@ SOURCES = {
     "ctx.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
+    "bin_batch.hip": [],
     "blend.hip": [],
     "param_bwd.hip": [],
     "tile_shim.hip": [],

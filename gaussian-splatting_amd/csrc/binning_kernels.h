@@ -1,0 +1,430 @@
+// Device code of the binning kernels (K2-K5), shared by the per-view entry points (binning.hip) and the batched,
+// host-wait-free ones (bin_batch.hip): every kernel body is a function of its block index and plain pointers,
+// and the __global__ wrappers of the two files only differ in where those come from.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;   // elements per block
+
+constexpr int RADIX_THREADS = 256;
+constexpr int RADIX_WAVES = RADIX_THREADS / 64;
+constexpr int RADIX_ITEMS = 16;
+constexpr int RADIX_TILE = RADIX_THREADS * RADIX_ITEMS;      // 4096 keys per workgroup
+constexpr int RADIX_WAVE_TILE = 64 * RADIX_ITEMS;            // 1024 keys per wave
+constexpr int RADIX_BINS = 256;
+
+struct Grid {
+    int tiles_x, tiles_y;
+};
+
+// tiles covered by gaussian g: rect clipped to the grid (tile_match only visits grid tiles,
+// setup_gpu.py:27-29); u32(depth)==0 entries are filtered out (rasterization.py:67)
+__device__ inline uint32_t tile_count(const int4 r, int depth, Grid g, int &x0, int &y0, int &h) {
+    x0 = max(r.x, 0);
+    y0 = max(r.y, 0);
+    const int x1 = min(r.z, g.tiles_x), y1 = min(r.w, g.tiles_y);
+    const int w = max(x1 - x0, 0);
+    h = max(y1 - y0, 0);
+    return depth == 0 ? 0u : (uint32_t)w * (uint32_t)h;
+}
+
+// Wave64 inclusive scans on the DPP crossbar: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then the last lane of
+// row 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31).  Lanes without a source
+// take the identity.  Six VALU steps; a __shfl_up ladder is six dependent trips through the LDS crossbar.
+#define GS_DPP_SCAN(OP, IDENT)                                                                        \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x111, 0xf, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x112, 0xf, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x114, 0xf, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x118, 0xf, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x142, 0xa, 0xf, false));   \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x143, 0xc, 0xf, false));
+__device__ __forceinline__ uint32_t gs_add_u32(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t gs_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
+    GS_DPP_SCAN(gs_add_u32, 0u)
+    return v;
+}
+// running maximum (identity 0)
+__device__ inline uint32_t wave_inclusive_max(uint32_t v) {
+    GS_DPP_SCAN(gs_max_u32, 0u)
+    return v;
+}
+#undef GS_DPP_SCAN
+
+// block-wide exclusive scan of one value per thread (256 threads = 4 waves); returns the
+// exclusive prefix, *block_total gets the sum
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *block_total) {
+    __shared__ uint32_t wave_sums[SCAN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        const uint32_t s = wave_sums[w];
+        if (w < wave) base += s;
+        total += s;
+    }
+    __syncthreads();
+    *block_total = total;
+    return base + inc - v;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The 64 lanes of a wave hold runs of `cnt` consecutive output slots starting at `first` (its exclusive prefix).
+// Returns, for slot sbase + lane of the concatenation, the lane that owns it: every lane whose run starts inside
+// the window [sbase, sbase + 64) marks its first slot in the wave's LDS row, and a running maximum carries the
+// owner over the rest of its run (owners grow with the slot); slots before the window's first mark belong to the
+// run that was open at the end of the previous window (`carry`, wave-uniform, 0 at the start).  One LDS round
+// trip and six DPP steps per window -- a binary search over the prefix array is six dependent LDS reads, and the
+// kernels that walk rects are bound by exactly that latency.  LDS operations of one wave execute in order.
+__device__ __forceinline__ uint32_t slot_owner(uint32_t *mark_row, int lane, uint32_t cnt, uint32_t first,
+                                               uint32_t sbase, uint32_t &carry) {
+    mark_row[lane] = 0u;
+    wave_lds_sync();
+    if (cnt != 0u && first >= sbase && first < sbase + 64u) mark_row[first - sbase] = (uint32_t)lane + 1u;
+    wave_lds_sync();
+    uint32_t m = wave_inclusive_max(mark_row[lane]);
+    m = max(m, carry);
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+    wave_lds_sync();                  // the row is rewritten by the next window
+    return m - 1u;                    // a slot below the wave's total always has an owner (m >= 1)
+}
+
+// K2'a: per-block totals of counts taken in depth order
+__device__ __forceinline__ void sorted_block_sums_body(int bid, int N, const int32_t *__restrict__ perm,
+                                                                         const uint32_t *__restrict__ counts,
+                                                                         uint32_t *__restrict__ block_sums) {
+    const int base = bid * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++)
+        if (base + k < N) sum += counts[perm[base + k]];
+    uint32_t total;
+    block_exclusive_scan(sum, &total);
+    if (threadIdx.x == 0) block_sums[bid] = total;
+}
+
+// K2'b: single block turns block_sums into exclusive block offsets
+// (*total_out, if given, receives the grand total: the number of pairs D of the view)
+__device__ __forceinline__ void scan_blocks_body(int bid, int nblocks, uint32_t *__restrict__ block_sums,
+                                                 uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0u;
+        const uint32_t inc = wave_inclusive_scan(v);
+        if (lane == 63) wave_sums[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, chunk_total = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) wbase += wave_sums[w];
+            chunk_total += wave_sums[w];
+        }
+        const uint32_t carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + wbase + inc - v;   // D < 2^31 is enforced on the host
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + chunk_total;
+        __syncthreads();
+    }
+    if (total_out && threadIdx.x == 0) *total_out = carry_s;     // behind the loop's last barrier
+}
+
+// K2'c: exclusive offsets per sorted position
+__device__ __forceinline__ void sorted_offsets_body(int bid, int N, const int32_t *__restrict__ perm,
+                                                                      const uint32_t *__restrict__ counts,
+                                                                      const uint32_t *__restrict__ block_offsets,
+                                                                      uint32_t *__restrict__ offsets) {
+    const int base = bid * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t c[SCAN_ITEMS];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        c[k] = (base + k < N) ? counts[perm[base + k]] : 0u;
+        sum += c[k];
+    }
+    uint32_t total;
+    uint32_t run = block_offsets[bid] + block_exclusive_scan(sum, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < N) offsets[base + k] = run;
+        run += c[k];
+    }
+}
+
+// ------------------------------------------------------------------ culled variants of K2 / K3
+// The reference's rect (Q8/Q9) is the bounding square of 3 sigma of the LARGER axis: about half of its
+// tiles are never reached by the ellipse at alpha >= 1/255.  With the packed blend records at hand
+// the same exact box test the blend kernels use when staging decides per (gaussian, tile) pair, so
+// pairs that cannot change any pixel are never emitted, sorted or staged.  A list built this way is
+// the reference's list with those entries removed (same order); images and gradients are unchanged.
+struct CullBox {
+    float tile, off;   // tile size in pixels, pixel_offset
+};
+
+__device__ __forceinline__ bool pair_may_contribute(const float4 geo, const float4 con, int tx, int ty, CullBox cb) {
+    const float xlo = (float)tx * cb.tile - cb.off, ylo = (float)ty * cb.tile - cb.off;
+    return gs_box_may_contribute(geo, con, xlo, xlo + cb.tile - 1.0f, ylo, ylo + cb.tile - 1.0f);
+}
+
+// One wave per 64 consecutive gaussians; the wave walks the concatenation of their rects 64 pairs at a
+// time (slot_owner finds each pair's gaussian, as in K3), so a gaussian covering thousands of tiles does not
+// serialise its wave.  CULL_EMIT = false: counts[g] <- pairs that pass.  CULL_EMIT = true (gaussians taken
+// in depth order through perm): the passing pairs are written from offsets[first position of the wave]
+// on, compacted with a ballot, i.e. in (depth order, tile order).
+template <bool CULL_EMIT>
+__device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t *__restrict__ perm,
+                                                           const int4 *__restrict__ rect,
+                                                           const int32_t *__restrict__ depth, Grid grid,
+                                                           const float4 *__restrict__ rec, CullBox cb,
+                                                           uint32_t *__restrict__ counts,
+                                                           const uint32_t *__restrict__ offsets, uint32_t D,
+                                                           uint32_t *__restrict__ tile_keys,
+                                                           int32_t *__restrict__ vals) {
+    __shared__ uint32_t s_first[4][64];  // exclusive prefix of rect sizes within the wave
+    __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
+    __shared__ float4 s_geo[4][64], s_con[4][64];
+    __shared__ uint32_t s_pass[4][64];
+    __shared__ uint32_t s_mark[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = (bid * 4 + wave) * 64;
+    const int i = i0 + lane;
+    uint32_t cnt = 0;
+    int x0 = 0, y0 = 0, h = 1, g = 0;
+    float4 geo = make_float4(0.f, 0.f, 0.f, 0.f), con = geo;
+    if (i < N) {
+        g = CULL_EMIT ? perm[i] : i;
+        cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
+        if (cnt) {
+            geo = rec[(size_t)g * 4];
+            con = rec[(size_t)g * 4 + 1];
+        }
+    }
+    const uint32_t inc = wave_inclusive_scan(cnt);
+    const uint32_t first = inc - cnt;
+    s_first[wave][lane] = first;
+    s_info[wave][lane] = make_int4(x0, y0, h, g);
+    s_geo[wave][lane] = geo;
+    s_con[wave][lane] = con;
+    s_pass[wave][lane] = 0u;
+    const uint32_t wave_total = __shfl(inc, 63, 64);   // 0 when the whole wave is past N
+    uint32_t out = (CULL_EMIT && i0 < N) ? offsets[i0] : 0u;
+    uint32_t carry = 0;
+    for (uint32_t sbase = 0; sbase < wave_total; sbase += 64) {      // wave-uniform trip count
+        const uint32_t sidx = sbase + lane;
+        const int lo = (int)slot_owner(s_mark[wave], lane, cnt, first, sbase, carry);
+        bool pass = false;
+        int tx = 0, ty = 0;
+        if (sidx < wave_total) {
+            const int4 inf = s_info[wave][lo];
+            const uint32_t local = sidx - s_first[wave][lo];
+            tx = inf.x + (int)(local / (uint32_t)inf.z);
+            ty = inf.y + (int)(local % (uint32_t)inf.z);
+            pass = pair_may_contribute(s_geo[wave][lo], s_con[wave][lo], tx, ty, cb);
+        }
+        if (CULL_EMIT) {
+            const unsigned long long m = __ballot(pass);
+            if (pass) {
+                const uint32_t pos = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < D) {     // always true: the count pass ran the same test on the same data
+                    tile_keys[pos] = (uint32_t)(tx * grid.tiles_y + ty);
+                    vals[pos] = s_info[wave][lo].w;
+                }
+            }
+            out += (uint32_t)__popcll(m);
+        } else if (pass) {
+            atomicAdd(&s_pass[wave][lo], 1u);
+        }
+    }
+    if (!CULL_EMIT) {
+        __syncthreads();
+        if (i < N) counts[i] = s_pass[wave][lane];
+    }
+}
+
+// ---------------------------------------------------------------------------- radix sort pass
+// digit = (key >> shift) & mask, at most 8 bits.  Block b owns keys [b*4096, (b+1)*4096).
+
+__device__ __forceinline__ void radix_hist_body(int bid, uint32_t n, const uint32_t *__restrict__ keys,
+                                                                   int shift, uint32_t mask, uint32_t nblocks,
+                                                                   uint32_t *__restrict__ table) {
+    __shared__ uint32_t h[RADIX_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = bid * (uint32_t)RADIX_TILE;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);   // base is a multiple of 4096
+#pragma unroll
+    for (int k = 0; k < RADIX_ITEMS / 4; k++) {
+        const uint32_t e = (k * RADIX_THREADS + threadIdx.x) * 4u;
+        const uint32_t i = base + e;
+        if (i + 3 < n) {
+            const uint4 v = k4[k * RADIX_THREADS + threadIdx.x];
+            atomicAdd(&h[(v.x >> shift) & mask], 1u);
+            atomicAdd(&h[(v.y >> shift) & mask], 1u);
+            atomicAdd(&h[(v.z >> shift) & mask], 1u);
+            atomicAdd(&h[(v.w >> shift) & mask], 1u);
+        } else {
+            for (uint32_t j = i; j < n && j < i + 4; j++) atomicAdd(&h[(keys[j] >> shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    table[threadIdx.x * nblocks + bid] = h[threadIdx.x];
+}
+
+// one workgroup per digit: table[d][b] <- keys with digit d in blocks before b; totals[d] <- keys
+// with digit d.  (No atomics: thousands of same-address atomics serialise at ~12 ns each.)
+__device__ __forceinline__ void radix_scan_body(int bid, uint32_t nblocks, uint32_t *__restrict__ table,
+                                                                   uint32_t *__restrict__ totals) {
+    const uint32_t d = bid;
+    uint32_t *row = table + (size_t)d * nblocks;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblocks; base += RADIX_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(v, &total);
+        if (i < nblocks) row[i] = carry + excl;
+        carry += total;
+    }
+    if (threadIdx.x == 0) totals[d] = carry;
+}
+
+// vals_in == nullptr: the value of key i is i (first pass of the depth sort).
+// keys_out == nullptr: only the values are wanted (last pass of the depth sort).
+// NBITS (digit width) is a template parameter: the ballot matching below is the kernel's cost (it is bound
+// by instruction issue, not by HBM), and a runtime width puts a branch around every one of its steps.
+template <int NBITS>
+__device__ __forceinline__ void radix_scatter_body(int bid,
+    uint32_t n, const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift, uint32_t mask,
+    uint32_t nblocks, const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals) {
+    __shared__ uint32_t s_cnt[RADIX_WAVES][RADIX_BINS];   // per-wave digit counts -> exclusive wave bases
+    __shared__ uint32_t s_lbase[RADIX_BINS];              // where digit d starts inside this block
+    __shared__ uint32_t s_gbase[RADIX_BINS];              // global start of (d, block) minus s_lbase[d]
+    __shared__ uint32_t s_keys[RADIX_TILE];
+    __shared__ int32_t s_vals[RADIX_TILE];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t base = bid * (uint32_t)RADIX_TILE;
+    if (base >= n) return;     // whole workgroup (a grid sized by an upper bound of n); before any barrier
+    const uint32_t wbase = base + (uint32_t)w * RADIX_WAVE_TILE;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    for (int c = t; c < RADIX_WAVES * RADIX_BINS; c += RADIX_THREADS) (&s_cnt[0][0])[c] = 0u;
+
+    // wave-striped arrangement: the block's key order is (wave, item, lane)
+    uint32_t key[RADIX_ITEMS], rank[RADIX_ITEMS];
+    int32_t val[RADIX_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RADIX_ITEMS; k++) {
+        const uint32_t i = wbase + k * 64 + lane;
+        key[k] = 0xFFFFFFFFu;
+        val[k] = 0;
+        if (i < n) {
+            key[k] = keys_in[i];
+            val[k] = vals_in ? vals_in[i] : (int32_t)i;
+        }
+    }
+    __syncthreads();
+
+    // plain LDS accesses: a volatile pointer here decays to a generic one and every counter access becomes a
+    // flat load / store with a full wait.  LDS operations of one wave execute in order; the fences keep the
+    // compiler from moving them across each other.
+    uint32_t *cnt = &s_cnt[w][0];
+#pragma unroll
+    for (int k = 0; k < RADIX_ITEMS; k++) {
+        const bool valid = wbase + k * 64 + lane < n;
+        const uint32_t d = (key[k] >> shift) & mask;
+        // lanes of this wave holding the same digit: per bit, keep the lanes whose bit equals mine.
+        // ~(ballot ^ m) with m = all ones where my bit is set: one xnor + one and per half and bit.
+        const unsigned long long vb = __ballot(valid);
+        uint32_t peers_lo = (uint32_t)vb, peers_hi = (uint32_t)(vb >> 32);
+#pragma unroll
+        for (int b = 0; b < NBITS; b++) {
+            const uint32_t bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit != 0u);
+            const uint32_t m = 0u - bit;
+            peers_lo &= ~((uint32_t)bal ^ m);
+            peers_hi &= ~((uint32_t)(bal >> 32) ^ m);
+        }
+        const unsigned long long peers = ((unsigned long long)peers_hi << 32) | peers_lo;
+        const uint32_t r = __popc(peers_lo & (uint32_t)lt) + __popc(peers_hi & (uint32_t)(lt >> 32));
+        const uint32_t prev = cnt[d];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && r == 0) cnt[d] = prev + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        rank[k] = prev + r;     // position among this wave's keys of digit d
+    }
+    __syncthreads();
+
+    {   // thread t = digit t
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < RADIX_WAVES; ww++) {
+            const uint32_t c = s_cnt[ww][t];
+            s_cnt[ww][t] = run;
+            run += c;
+        }
+        uint32_t block_total, all;
+        const uint32_t excl = block_exclusive_scan(run, &block_total);
+        const uint32_t dbase = block_exclusive_scan(totals[t], &all);   // keys with a smaller digit
+        s_lbase[t] = excl;
+        s_gbase[t] = dbase + table[(size_t)t * nblocks + bid] - excl;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < RADIX_ITEMS; k++) {
+        if (wbase + k * 64 + lane < n) {
+            const uint32_t d = (key[k] >> shift) & mask;
+            const uint32_t pos = s_lbase[d] + s_cnt[w][d] + rank[k];
+            s_keys[pos] = key[k];
+            s_vals[pos] = val[k];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t count = min((uint32_t)RADIX_TILE, n - base);
+    for (uint32_t i = t; i < count; i += RADIX_THREADS) {
+        const uint32_t kk = s_keys[i];
+        const uint32_t pos = s_gbase[(kk >> shift) & mask] + i;
+        if (keys_out) keys_out[pos] = kk;
+        vals_out[pos] = s_vals[i];
+    }
+}
+
+// K5: per-tile [start,end) from the sorted tile ids
+__device__ __forceinline__ void ranges_body(int bid, uint32_t D, const uint32_t *__restrict__ tile_keys,
+                                                     int32_t *__restrict__ ranges) {
+    const uint32_t i = bid * 256u + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t t = tile_keys[i];
+    if (i == 0) {
+        ranges[2 * t] = 0;
+    } else {
+        const uint32_t p = tile_keys[i - 1];
+        if (p != t) {
+            ranges[2 * p + 1] = (int32_t)i;
+            ranges[2 * t] = (int32_t)i;
+        }
+    }
+    if (i == D - 1) ranges[2 * t + 1] = (int32_t)D;
+}
+
+}  // namespace

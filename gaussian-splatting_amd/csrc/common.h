@@ -63,7 +63,9 @@ struct gs_ctx {
     gs_buf stats_words;   // u64[8] counters of gs_view_stats
     gs_buf det_partials;  // deterministic backward: float[nsub][D][12] per-(tile, gaussian) partial gradients
     gs_buf det_sort;      // deterministic backward: 2 x u32[D] keys + 2 x i32[D] positions (sort by gaussian)
-    uint64_t *total_host = nullptr;   // pinned, 2 words
+    gs_buf bounds;        // gs_bin_bounds_batch: per-block partials and the per-view (pairs, max depth) words
+    hipEvent_t bounds_event = nullptr;
+    uint64_t *total_host = nullptr;   // pinned: 2 words (D, max depth) + 2 per view of a batch
     hipEvent_t count_event = nullptr; // recorded behind the copy of D into total_host (gs_bin_count*_begin)
     int32_t count_pending_N = -1;     // N of a gs_bin_count*_begin whose gs_bin_count_end has not run
     // state carried from gs_bin_count to gs_bin_fill

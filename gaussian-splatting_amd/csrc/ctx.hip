@@ -47,7 +47,7 @@ extern "C" int gs_ctx_create(int device, void *stream, gs_ctx **out) {
     gs_ctx *c = new gs_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;
-    hipError_t e = hipHostMalloc((void **)&c->total_host, 2 * sizeof(uint64_t), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void **)&c->total_host, (2 + 2 * GS_BIN_MAX_VIEWS) * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         delete c;
         return gs_set_error(GS_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
@@ -166,13 +166,14 @@ extern "C" int gs_ctx_destroy(gs_ctx *ctx) {
     gs_buf *bufs[] = {&ctx->counts, &ctx->offsets, &ctx->block_sums, &ctx->total, &ctx->depth_sort,
                       &ctx->keys_tmp, &ctx->vals_tmp, &ctx->radix_table, &ctx->packed, &ctx->grad_rows,
                       &ctx->tile_scratch, &ctx->loss_partials, &ctx->stats_words, &ctx->det_partials, &ctx->det_sort,
-                      &ctx->tile_order_buf};
+                      &ctx->tile_order_buf, &ctx->bounds};
     for (gs_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (gs_prof_span &sp : ctx->prof_spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }
     for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     if (ctx->total_host) (void)hipHostFree(ctx->total_host);
     if (ctx->count_event) (void)hipEventDestroy(ctx->count_event);
+    if (ctx->bounds_event) (void)hipEventDestroy(ctx->bounds_event);
     delete ctx;
     return GS_OK;
 }

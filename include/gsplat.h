@@ -171,6 +171,36 @@ int gs_bin_count_culled_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touch
                               float pixel_offset);
 int gs_bin_count_end(gs_ctx *ctx, int64_t *D_host);
 
+/* The culled lists of up to GS_BIN_MAX_VIEWS views per call, built by launches that each cover every view of the
+ * batch, with no host wait (no counterpart in the reference, which builds one view's lists at a time on the host:
+ * rasterization.py:6-25,57-71).  A training step is bound by the number of short dependent launches its views
+ * need, and the per-view calls above need about 25 per view plus one host wait; this form needs about 20 per
+ * BATCH and none.
+ *   records        the view's 64-byte blend records (gs_preprocess_batch_records); the box test reads them
+ *   vals[capacity] gaussian ids, per tile in (depth, gaussian) order -- the array gs_bin_fill_culled writes
+ *   ranges[tiles,2]
+ *   D_dev[2]       DEVICE memory: [0] = pairs in the list, [1] = pairs found ([1] > [0]: capacity was too small and
+ *                  the list holds the first `capacity` pairs in depth order -- never an out-of-bounds access)
+ * gs_bin_bounds_batch returns per view (bounds_host[2v], bounds_host[2v+1]) = (number of rect pairs of
+ * rasterization.py:6-25 -- an upper bound of the culled count, to size vals with --, largest u32(depth) among
+ * them), with ONE host wait for the whole batch.  gs_bin_culled_batch sorts the low depth_bits bits of the depth
+ * keys (bits_of(max depth) from the bounds; 32 is always right) and waits for nothing.  The blend calls take
+ * D = capacity for lists built this way (ranges bound every read of vals); the deterministic backward needs the
+ * list's true length and is not supported on them. */
+#define GS_BIN_MAX_VIEWS 8
+typedef struct {
+    const int32_t *tiles_touched;   /* [N,4]  */
+    const int32_t *depths;          /* [N]    */
+    const float *records;           /* [N,16] */
+    int32_t *vals;                  /* [capacity] out */
+    int32_t *ranges;                /* [tiles,2]  out */
+    int64_t *D_dev;                 /* [2]        out, device */
+} gs_view_bin;
+int gs_bin_bounds_batch(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_bin *views, int32_t res_w,
+                        int32_t res_h, int32_t tile_size, int64_t *bounds_host);
+int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_bin *views, int32_t res_w,
+                        int32_t res_h, int32_t tile_size, float pixel_offset, int32_t depth_bits, int64_t capacity);
+
 /* Replaces gpu_rasterize forward (rasterization.py:27-107 + kernel rasterize,
  * setup_gpu.py:46-100), c_rasterize/rasterize_tile (rasterization.py:109-153, rasterize.c:27-132)
  * and rasterize (rasterization.py:155-215): one launch for the whole frame.

@@ -1102,3 +1102,69 @@ def test_view_stats_from_the_library_match_a_recomputation(gpu_ctx):
     assert s["bytes_blend_backward"] == visited * 76 + W * H * 20 and s["bytes_tile_sort"] == 40 * b.D
     only = gs.view_stats(gpu_ctx, None, b, None)
     assert only["n_visible"] == -1 and only["visited"] == -1 and only["max_tile_list"] == s["max_tile_list"]
+
+
+@pytest.mark.parametrize("tile,W,H,n_views", [(16, 640, 360, 5), (32, 500, 300, 3), (16, 333, 211, 8)])
+def test_batched_binning_equals_the_per_view_calls(gpu_ctx, tile, W, H, n_views):
+    """gs_bin_culled_batch (one grid row per view, no host wait, D on the device) against gs_bin_count_culled +
+    gs_bin_fill_culled view by view: vals and ranges bit for bit, D_dev = (D, D); the bounds are the rect-pair
+    counts of the exact path (gs_bin_count) and the largest depth key.  A capacity below D truncates the list to
+    its first pairs in depth order and reports it."""
+    import torch
+    import gsplat_amd as gs
+    from bench import make_views
+    cam, R, t, g, rs = synth_scene(60_000, W, H, seed=11, log_scale=(0.5, 3.0))
+    pipe = gs.SplatPipeline(g, rs, tile_size=tile, opacity_is_logit=False, ctx=gpu_ctx)
+    views = make_views(gs, cam, n_views)
+    pres = pipe.preprocess_batch(views, records=True)
+    bounds = gs.api.bin_bounds_batch(gpu_ctx, pres, rs, tile)
+    batch = gs.api.bin_culled_batch(gpu_ctx, pres, rs, tile, pipe.pixel_offset)
+    cap = max(b[0] for b in bounds)
+    for k, p in enumerate(pres):
+        exact = gs.match_gaus_to_tiles(gpu_ctx, None, None, p["rect"], p["radii"], p["depths"], rs, tile, want_keys=False)
+        assert bounds[k][0] == exact.D
+        r = p["rect"]
+        tx_n, ty_n = -(-rs[0] // tile), -(-rs[1] // tile)
+        area = (r[:, 2].clamp(max=tx_n) - r[:, 0].clamp(min=0)).clamp(min=0) * (r[:, 3].clamp(max=ty_n) - r[:, 1].clamp(min=0)).clamp(min=0)
+        live = (area > 0) & (p["depths"] != 0)          # the gaussians that own a pair (setup_gpu.py:27-29)
+        assert bounds[k][1] == int(p["depths"][live].max().item())
+        tok = pipe.forward_begin(views[k], pre=p)
+        ref = pipe.forward_bin(tok)
+        b = batch[k]
+        assert b.D == cap and b.true_D() == ref.D and b.D_dev.tolist() == [ref.D, ref.D]
+        assert torch.equal(b.ranges, ref.ranges)
+        assert torch.equal(b.vals[:ref.D], ref.vals)
+        # the image from the device-counted list is the image from the per-view list
+        img_b, _ = pipe.forward_blend(dict(pre=p, opac=tok["opac"], binning=b, c=gpu_ctx))
+        img_r, _ = pipe.forward_blend(dict(pre=p, opac=tok["opac"], binning=ref, c=gpu_ctx))
+        assert torch.equal(img_b, img_r)
+    # 32 depth bits (no bound known) give the same lists
+    again = gs.api.bin_culled_batch(gpu_ctx, pres, rs, tile, pipe.pixel_offset, depth_bits=32, capacity=cap)
+    for a, b in zip(again, batch):
+        assert torch.equal(a.ranges, b.ranges) and torch.equal(a.vals[:b.true_D()], b.vals[:b.true_D()])
+    # too small a capacity: reported, and nothing is written past it
+    D0 = batch[0].true_D()
+    small = gs.api.bin_culled_batch(gpu_ctx, pres[:1], rs, tile, pipe.pixel_offset, depth_bits=32, capacity=D0 // 2)[0]
+    kept, found = small.D_dev.tolist()
+    assert (kept, found) == (D0 // 2, D0)
+    with pytest.raises(gs.GsError):
+        small.true_D()
+    lens = (small.ranges[:, 1] - small.ranges[:, 0])
+    assert int(lens.sum().item()) == D0 // 2 and int(small.ranges.max().item()) <= D0 // 2
+
+
+def test_batched_binning_edge_cases(gpu_ctx):
+    """No visible gaussian in a view, a single view, more views than a batch holds."""
+    import torch
+    import gsplat_amd as gs
+    from bench import make_views
+    cam, R, t, g, rs = synth_scene(3000, 160, 96, seed=5)
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    views = make_views(gs, cam, 2)
+    pres = pipe.preprocess_batch(views, records=True)
+    pres[1]["depths"].zero_()            # u32(depth) == 0: filtered out (rasterization.py:67)
+    out = gs.api.bin_culled_batch(gpu_ctx, pres, rs, 16, pipe.pixel_offset)
+    assert out[1].D_dev.tolist() == [0, 0] and int(out[1].ranges.abs().sum().item()) == 0
+    assert out[0].true_D() > 0
+    with pytest.raises(gs.GsError):
+        gs.api.bin_culled_batch(gpu_ctx, pres * 5, rs, 16, pipe.pixel_offset, capacity=10)

@@ -11,7 +11,7 @@ LIB = os.path.join(ROOT, "tools", "libgsplat_stamp.so")
 
 
 def build():
-    srcs = ["ctx.hip", "preprocess.hip", "binning.hip", "blend.hip", "param_bwd.hip", "tile_shim.hip", "train.hip", "stats.hip"]
+    srcs = ["ctx.hip", "preprocess.hip", "binning.hip", "bin_batch.hip", "blend.hip", "param_bwd.hip", "tile_shim.hip", "train.hip", "stats.hip"]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DGS_STAMPS",
            "-fno-slp-vectorize", "-shared", "-o", LIB] + [os.path.join(PKG, "csrc", s) for s in srcs]
     subprocess.check_call(cmd)

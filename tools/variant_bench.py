@@ -6,7 +6,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "gaussian-splatting_amd")
-SRCS = ["ctx.hip", "preprocess.hip", "binning.hip", "blend.hip", "param_bwd.hip", "tile_shim.hip", "train.hip", "stats.hip"]
+SRCS = ["ctx.hip", "preprocess.hip", "binning.hip", "bin_batch.hip", "blend.hip", "param_bwd.hip", "tile_shim.hip", "train.hip", "stats.hip"]
 
 
 def lib_path(name):
