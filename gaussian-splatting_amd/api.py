@@ -84,6 +84,7 @@ class DeviceContext:
 
     def set_option(self, name, value):
         check(self.lib.gs_ctx_set_option(self.handle, name.encode(), int(value)), "gs_ctx_set_option")
+        self.options = dict(getattr(self, "options", {}), **{name: int(value)})
 
     def profile(self, enable=True):
         """Bracket every kernel launch with HIP events (see read_profile)."""

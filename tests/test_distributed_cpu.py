@@ -70,6 +70,16 @@ class FakeLib:
     def gs_bin_fill_culled(self, h, *a):
         return 0
 
+    def gs_bin_bounds_batch(self, h, n, n_views, views, w, hh, ts, out):
+        for k in range(n_views):
+            out[2 * k], out[2 * k + 1] = 7, 1000
+        return 0
+
+    def gs_bin_culled_batch(self, h, n, n_views, views, w, hh, ts, off, depth_bits, capacity):
+        assert capacity == 7 and depth_bits == 10
+        self.log.append(("bin", n_views))
+        return 0
+
     def _view(self, h):
         return float(_f32(self.records[h], 1)[0])
 
@@ -176,14 +186,14 @@ def _check(grads, n_views, what):
     assert np.all(grads.sh.numpy() == count) and np.all(grads.opacity.numpy() == count), what
 
 
-def _run(n_views, lanes):
+def _run(n_views, lanes, **step_args):
     import gsplat_amd as gs
     lib = FakeLib()
     pipe = gs.SplatPipeline(_scene(), [W, H], ctx=FakeCtx(lib))
     grads = gs.FlatGrads(N, torch.device("cpu"))
     grads.flat.fill_(123.0)                               # stale content must be overwritten, not added to
     views, targets = _views_targets(gs, n_views)
-    loss, n_local = gs.train_step(pipe, views, targets, grads, concurrent_views=lanes)
+    loss, n_local = gs.train_step(pipe, views, targets, grads, concurrent_views=lanes, **step_args)
     return lib, grads, float(loss), n_local
 
 
@@ -196,6 +206,17 @@ def test_one_rank_real_step_code_matches_closed_form(n_views, lanes):
     k8 = [e for e in lib.log if e[0] == "k8"]
     if n_views >= 4 and lanes == 4:      # early launch (write) for the first two lanes' views, late launch adds
         assert k8[0][3] == 0 and k8[-1][3] == 1 and k8[0][2] + k8[-1][2] == n_views
+    assert sum(e[1] for e in lib.log if e[0] == "k1") == n_views
+
+
+@pytest.mark.parametrize("n_views,lanes,group", [(8, 4, 4), (5, 3, 2), (1, 1, 4), (8, 2, 8)])
+def test_one_rank_step_with_batched_lists_matches_closed_form(n_views, lanes, group):
+    """train_step(batch_binning=True): lists per group of views (gs_bin_culled_batch), blends on side streams."""
+    lib, grads, loss, n_local = _run(n_views, lanes, batch_binning=True, bin_group=group)
+    _check(grads, n_views, f"{n_views} views, groups of {group}")
+    assert abs(loss - _expected(n_views)[3]) < 1e-4
+    assert sum(e[1] for e in lib.log if e[0] == "bin") == n_views
+    assert max(e[1] for e in lib.log if e[0] == "bin") <= group
     assert sum(e[1] for e in lib.log if e[0] == "k1") == n_views
 
 

@@ -130,6 +130,15 @@ def test_config2_train_step_8_views_on_4_lanes_equals_per_view_sum(gpu_ctx, benc
         a, b = getattr(multi, name), getattr(single, name)
         scale = float(b.abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, name
+    # the same step with the lists built per batch of views and their lengths kept on the device
+    batched = gs.FlatGrads(N2, dev)
+    for group in (4, 8):
+        loss_b, n = gs.train_step(pipe, views, targets, batched, concurrent_views=4, batch_binning=True, bin_group=group)
+        torch.cuda.synchronize()
+        assert n == 8 and abs(float(loss_b) - total) <= 1e-5 * total
+        for name in ("means", "log_scales", "quats", "opacity", "sh"):
+            a, b = getattr(batched, name), getattr(single, name)
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (name, group)
 
 
 def test_config2_band_gradients_vs_fp64_autograd(gpu_ctx, bench_scene):

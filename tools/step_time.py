@@ -1,6 +1,6 @@
-"""train_step time of the bench workload under scheduler variants: "t1" / "t0" = one host thread per lane or one
-for all, followed by the number of lanes.
-    python tools/step_time.py t1,4 t0,4 t1,3"""
+"""train_step time of the bench workload under scheduler variants: "bG,L" = lists built per batch of G views
+(gs_bin_culled_batch) and L streams; "p,L" = per-view lists on L lanes.
+    python tools/step_time.py b4,4 b2,4 b8,4 p,4"""
 import os
 import sys
 
@@ -19,13 +19,15 @@ def main():
     g, cam = make_scene(N, W, H, (1.0, 3.0))
     ctx, _, _ = gs.setup_gpu(0)
     pipe = gs.SplatPipeline(g, [W, H], ctx=ctx)
-    views = make_views(gs, cam, 8)
-    targets = [torch.rand(W, H, 3, device=ctx.device)] * 8
+    nv = int(os.environ.get("GS_VIEWS", 8))
+    views = make_views(gs, cam, 8)[:nv]
+    targets = [torch.rand(W, H, 3, device=ctx.device)] * nv
     grads = gs.FlatGrads(N, ctx.device)
     ref = None
     for variant in sys.argv[1:] or [""]:
-        th, nl = (variant or "t1,4").split(",")
-        fn = lambda: pl.train_step(pipe, views, targets, grads, concurrent_views=int(nl), lane_threads=th == "t1")
+        how, nl = (variant or "p,4").split(",")
+        fn = lambda: pl.train_step(pipe, views, targets, grads, concurrent_views=int(nl), batch_binning=how[0] == "b",
+                                   bin_group=int(how[1:] or 4))
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
