@@ -265,6 +265,7 @@ def main():
                 if "valu_issue_frac" in e:
                     roofline["valu_issue_frac"] = e["valu_issue_frac"]
                     roofline["salu_issue_frac"] = e.get("salu_issue_frac")
+                    roofline["lds_busy_frac"] = e.get("lds_busy_frac")
                     roofline["valu_wave_instructions"] = int(e["SQ_INSTS_VALU"])
                     roofline["counter_clock_ghz"] = e.get("clock_ghz")
             elif not same_tree:
