@@ -6,6 +6,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`--gpus N` is checked, not trusted: with N > 1 and no torch.distributed environment (WORLD_SIZE unset) this
+process starts the N ranks itself (a child `python -m torch.distributed.run ...` of this same file, before any GPU
+call) and exits with the child's status; with WORLD_SIZE set and different from N it exits non-zero.  The line
+reports `ranks_seen` = what an all-reduce of ones over the process group returned.
+
 One process per GPU.  Weak scaling: every rank renders 8 views per step (global batch 8*N views,
 sharded round-robin over the ranks; --views-per-rank 0 --views 8 gives the fixed 8-view global batch
 instead); per-gaussian gradients [N*59] fp32 are summed with one RCCL all-reduce inside the timed
@@ -29,6 +34,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_SUMMARY = "r03_pmc_summary.json"
+# stages whose launch is several kernels: the counters of the stage are the sums over its parts
+PMC_PARTS = {"bin_sort": ("tile_hist", "tile_scan", "tile_scatter")}
+LISTS_NOTE = {
+    "exact": "SplatPipeline(cull_tiles=False): the reference's own (tile, depth) lists -- keys, values and ranges "
+             "bit-exact against the reference",
+    "culled": "SplatPipeline(cull_tiles=True): the exact lists minus the (gaussian, tile) pairs that cannot reach "
+              "alpha >= 1/255 in the tile, same order; images bit-identical, gradients equal to float-atomics rounding",
+}
 FP32_VALU_PEAK_TFLOPS = 157.3
 
 
@@ -45,7 +59,10 @@ def parse():
     ap.add_argument("--log-scale", type=float, nargs=2, default=(1.0, 3.0))
     ap.add_argument("--cpu-views", type=int, default=32, help="frames rendered by the CPU baseline (about 0.4 s each on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-lists", action="store_true", help="skip the timed step on the reference's own lists")
+    ap.add_argument("--lists", choices=["exact", "culled"], default="exact",
+                    help="exact (default): the reference's own (tile, depth) lists, keys / values / ranges bit-exact; "
+                         "culled: the same lists minus the pairs that cannot change a pixel (same images)")
+    ap.add_argument("--no-other-lists", action="store_true", help="skip the timed step on the other list kind")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the single-stream per-kernel timing pass")
     ap.add_argument("--kernel-timing", choices=["dominant", "all", "none"], default="dominant",
                     help="which kernels get HIP events inside the timed region")
@@ -103,8 +120,30 @@ def make_views(gs, cam, n_views):
     return views
 
 
+def launch_ranks(args):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks (one per GPU) as a child
+    torch.distributed.run of this file and return its exit status.  Nothing here touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     import torch
     import torch.distributed as dist
     import gsplat_amd as gs
@@ -135,7 +174,7 @@ def main():
     W, H, N = args.width, args.height, args.gaussians
     g, cam = make_scene(N, W, H, args.log_scale)
     ctx, queue, program = gs.setup_gpu(local_rank)
-    pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx)
+    pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx, cull_tiles=args.lists == "culled")
     weak = args.views_per_rank > 0
     n_views = 1 if args.forward_only else (args.views_per_rank * world if weak else args.views)
     views = make_views(gs, cam, n_views)
@@ -198,9 +237,14 @@ def main():
         c.set_option("profile_mask", 0x7FFFFFFF)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)      # what the process group really spans
     elapsed = float(t.item())
+    ranks_seen = int(round(float(ones.item())))
+    if ranks_seen != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the process group spans {ranks_seen} rank(s)")
     ms_per_step = elapsed * 1e3 / args.steps
     mpix = n_views * W * H / 1e6
     value = mpix / (ms_per_step / 1e3)
@@ -235,49 +279,92 @@ def main():
         dom = max((k for k in single if k in alg_bytes), key=lambda k: single[k]["ms_per_launch"] * single[k]["launches"])
     else:
         dom = max(timed, key=lambda k: timed[k][0]) if timed else None
+    # HBM bytes and instruction counts per launch from the PMC passes of THIS source tree on THIS workload
+    # (tools/pmc_collect.sh, tools/pmc_summary.py): refused when the kernels have changed since, or for another one
+    pmc, pmc_why = None, None
+    try:
+        cand = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
+        meta = cand.get("_meta", {})
+        if meta.get("source_sha16") != source_sha16():
+            pmc_why = f"none: profiles/{PMC_SUMMARY} was collected from another source tree"
+        elif (meta.get("gaussians", 1_000_000), meta.get("width", 1920), meta.get("height", 1080)) != (N, W, H) or \
+                tuple(meta.get("log_scale", (1.0, 3.0))) != tuple(args.log_scale) or meta.get("lists", "culled") != args.lists:
+            pmc_why = f"none: profiles/{PMC_SUMMARY} was collected on another workload"
+        else:
+            pmc = cand
+    except (OSError, ValueError):
+        pmc_why = f"none: no profiles/{PMC_SUMMARY}"
+
+    def stage_record(k):
+        """roofline record of one stage: algorithmic bytes / its duration ALONE on the chip against HBM peak, plus
+        what the counters say bounds it."""
+        dur_ms = single[k]["ms_per_launch"] if k in single else timed[k][0] / timed[k][1]
+        ab = alg_bytes.get(k)
+        achieved = ab / (dur_ms / 1e3) / 1e9 if ab else None
+        r = {"kernel": k, "bound": "hbm", "achieved": round(achieved, 2) if achieved else None,
+             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+             "traffic": None, "avg_launch_ms": round(dur_ms, 4),
+             "avg_launch_source": "HIP events around the launch, kernel alone on the chip (one stream)"
+             if k in single else "HIP events around the launch inside the timed region",
+             "algorithmic_bytes_per_launch": int(ab) if ab else None}
+        if k in timed:
+            r["in_step_launch_ms"] = round(timed[k][0] / timed[k][1], 4)
+        e = None
+        if pmc is not None:
+            # the tile sort is three kernels per pass: its counters are the sums over them
+            parts = [pmc[n] for n in PMC_PARTS.get(k, (k,)) if n in pmc]
+            if parts:
+                e = {}
+                for q in parts:
+                    w = q.get("launches_per_view", 1.0) if k in PMC_PARTS else 1.0     # e.g. two passes per sort
+                    for name in ("hbm_traffic_bytes", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"):
+                        if name in q:
+                            e[name] = e.get(name, 0.0) + q[name] * w
+        if e and "hbm_traffic_bytes" in e:
+            r["traffic"] = int(e["hbm_traffic_bytes"])
+            r["traffic_source"] = f"profiles/{PMC_SUMMARY} (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+        elif pmc_why:
+            r["traffic_source"] = pmc_why
+        if e and e.get("GRBM_GUI_ACTIVE") and "SQ_INSTS_VALU" in e:
+            cycles = e["GRBM_GUI_ACTIVE"] / 8.0
+            issue = {"valu": round(e["SQ_INSTS_VALU"] * 2.0 / (1024 * cycles), 4)}
+            if "SQ_INSTS_SALU" in e:
+                issue["salu"] = round(e["SQ_INSTS_SALU"] / (256 * cycles), 4)
+            if "SQ_LDS_IDX_ACTIVE" in e:
+                issue["lds"] = round(e["SQ_LDS_IDX_ACTIVE"] / (256 * cycles), 4)
+            top = max(issue, key=issue.get)
+            r["issue"] = {"bound": top, "frac": issue[top], "valu_issue_frac": issue.get("valu"),
+                          "salu_issue_frac": issue.get("salu"), "lds_busy_frac": issue.get("lds"),
+                          "valu_wave_instructions": int(e["SQ_INSTS_VALU"]),
+                          "note": "counter-derived: wave-instructions x 2 cycles / (1024 SIMDs x kernel cycles); scalar "
+                                  "instructions / (256 scalar units x cycles); LDS-array active cycles / (256 CUs x cycles)"}
+        return r
+
     roofline = None
     if dom:
-        dur_ms = single[dom]["ms_per_launch"] if dom in single else timed[dom][0] / timed[dom][1]
-        ab = alg_bytes.get(dom)
-        achieved = ab / (dur_ms / 1e3) / 1e9 if ab else None
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2) if achieved else None,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": None,
-                    "avg_launch_ms": round(dur_ms, 4),
-                    "avg_launch_source": "HIP events around the launch, kernel alone on the chip (one stream)"
-                    if dom in single else "HIP events around the launch inside the timed region",
-                    "algorithmic_bytes_per_launch": int(ab) if ab else None,
-                    "note": "the blend kernels are bound by vector-instruction issue, not by HBM or MFMA (no dense "
-                            "contraction): valu_issue_frac prices the counted wave-instructions at 2 cycles each"}
-        if dom in timed:
-            roofline["in_step_launch_ms"] = round(timed[dom][0] / timed[dom][1], 4)
-        # HBM bytes and instruction counts per launch from the PMC passes of THIS source tree (tools/pmc_collect.sh,
-        # tools/pmc_summary.py): refused when the kernels have changed since, or for another workload
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-            same_tree = pmc.get("_meta", {}).get("source_sha16") == source_sha16()
-            same_load = (N, W, H) == (1_000_000, 1920, 1080) and tuple(args.log_scale) == (1.0, 3.0)
-            if same_tree and same_load and dom in pmc:
-                e = pmc[dom]
-                if "hbm_traffic_bytes" in e:
-                    roofline["traffic"] = int(e["hbm_traffic_bytes"])
-                    roofline["traffic_source"] = "profiles/r02_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
-                if "valu_issue_frac" in e:
-                    roofline["valu_issue_frac"] = e["valu_issue_frac"]
-                    roofline["salu_issue_frac"] = e.get("salu_issue_frac")
-                    roofline["lds_busy_frac"] = e.get("lds_busy_frac")
-                    roofline["valu_wave_instructions"] = int(e["SQ_INSTS_VALU"])
-                    roofline["counter_clock_ghz"] = e.get("clock_ghz")
-            elif not same_tree:
-                roofline["traffic_source"] = "none: profiles/r02_pmc_summary.json was collected from another source tree"
-        except (OSError, ValueError):
-            pass
+        roofline = stage_record(dom)
+        roofline["note"] = ("frac is the HBM fraction the metric asks for; the blend kernels are bound by vector-instruction "
+                            "issue and wave life, not by HBM or MFMA (no dense contraction): see roofline.issue")
+        # the stage that IS bound by HBM and furthest from it: the tile sort
+        if "bin_sort" in single and dom != "bin_sort":
+            roofline["hbm_stage"] = stage_record("bin_sort")
+        # the whole step against the HBM roofline: algorithmic bytes of everything a step launches / step time
+        if not args.forward_only and stats["duplicates"] >= 0:
+            V = len(mine)
+            per_view = (stats["bytes_depth_sort"] + N * 56 + N * 16 + stats["bytes_duplicate"] + stats["bytes_tile_sort"] +
+                        stats["bytes_ranges"] + stats["bytes_blend_forward"] + 36 * P + stats["bytes_blend_backward"])
+            step_bytes = N * (240 + V * 91) + V * per_view + N * (236 + V * 71 + 236)
+            roofline["step_algorithmic_bytes"] = int(step_bytes)
+            roofline["step_hbm_frac"] = round(step_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["step_note"] = ("K1 N*(240+V*91) + V views x (depth sort, count, scan, duplicate, tile sort, ranges, K6, "
+                                     "loss 36*P, K7; view 0's D and D* taken for every view) + K8 N*(236+V*71+236)")
 
-    # ---- the bit-exact list path (cull_tiles=False: the reference's own (tile, depth) lists), same step
-    exact_lists = None
-    if rank == 0 and world == 1 and not args.forward_only and not args.no_exact_lists:
-        exact_pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx, cull_tiles=False)
-        run = lambda: gs.train_step(exact_pipe, views, targets, grads, concurrent_views=args.concurrent_views,
+    # ---- the same step on the other kind of lists
+    other_lists = None
+    if rank == 0 and world == 1 and not args.forward_only and not args.no_other_lists:
+        other_kind = "culled" if args.lists == "exact" else "exact"
+        other_pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx, cull_tiles=other_kind == "culled")
+        run = lambda: gs.train_step(other_pipe, views, targets, grads, concurrent_views=args.concurrent_views,
                                     k8_early_lanes=args.k8_early_lanes)
         for _ in range(3):
             run()
@@ -287,11 +374,10 @@ def main():
             run()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t1) * 1e3 / args.steps
-        _, se = exact_pipe.forward(views[0])
-        exact_lists = {"ms_per_step": round(ms, 3), "value": round(mpix / (ms / 1e3), 2), "unit": "Mpix/s",
-                       "duplicates_D": int(se["binning"].D),
-                       "note": "SplatPipeline(cull_tiles=False): keys, values and ranges bit-exact against the reference"}
-        del exact_pipe, se
+        _, se = other_pipe.forward(views[0])
+        other_lists = {"lists": other_kind, "ms_per_step": round(ms, 3), "value": round(mpix / (ms / 1e3), 2),
+                       "unit": "Mpix/s", "duplicates_D": int(se["binning"].D), "note": LISTS_NOTE[other_kind]}
+        del other_pipe, se
 
     # ---- CPU baseline: restatement of rasterize.c on the host cores (rank 0, N=1 only), bounded sample
     cpu_baseline = None
@@ -343,8 +429,10 @@ def main():
                                    "stays visible in every view",
                        "n_visible": n_visible, "duplicates_D": int(D), "visited_D_star": d_star,
                        "max_tile_list": max_len, "pixels_per_thread": 4,
-                       "concurrent_views_per_rank": args.concurrent_views},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "exact_lists": exact_lists, "kernels": kernels,
+                       "concurrent_views_per_rank": args.concurrent_views,
+                       "lists": args.lists, "lists_note": LISTS_NOTE[args.lists], "ranks_seen": ranks_seen},
+            "ranks_seen": ranks_seen,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "other_lists": other_lists, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

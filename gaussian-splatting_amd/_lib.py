@@ -58,6 +58,7 @@ SIGNATURES = {
     "gs_ctx_create": (ctypes.c_int, [ctypes.c_int, _P, ctypes.POINTER(_P)]),
     "gs_ctx_set_stream": (ctypes.c_int, [_P, _P]),
     "gs_ctx_destroy": (ctypes.c_int, [_P]),
+    "gs_ctx_info": (_I64, [_P, ctypes.c_char_p]),
     "gs_ctx_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, _I32]),
     "gs_profile_kernel_count": (ctypes.c_int, []),
     "gs_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "gs_bin_count_culled": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float,
                                            ctypes.POINTER(_I64)]),
     "gs_bin_count_culled_begin": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float]),
+    "gs_bin_count_begin": (ctypes.c_int, [_P, _I32, _P, _P, _I32, _I32, _I32]),
     "gs_bin_count_end": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
     "gs_bin_bounds_batch": (ctypes.c_int, [_P, _I32, _I32, ctypes.POINTER(GsViewBin), _I32, _I32, _I32, ctypes.POINTER(_I64)]),
     "gs_bin_culled_batch": (ctypes.c_int, [_P, _I32, _I32, ctypes.POINTER(GsViewBin), _I32, _I32, _I32, ctypes.c_float, _I32,

@@ -54,6 +54,8 @@ class DeviceContext:
         check(self.lib.gs_ctx_create(self.device_index, ctypes.c_void_p(self._stream_id), ctypes.byref(h)),
               "gs_ctx_create")
         self.handle = h
+        self.options = {}
+        self._clones = []       # weak references: options set later reach the contexts cloned from this one
 
     def sync_stream(self):
         """Make the native ctx launch on torch's current stream for this device."""
@@ -65,12 +67,18 @@ class DeviceContext:
     # streams and sibling contexts are handed out by the context, so that everything above it (SplatPipeline,
     # train_step) names no device runtime: a context of another kind can stand in this slot
     def clone(self):
-        """A second context (own workspace arena) on the same device."""
-        return DeviceContext(self.device_index)
+        """A second context (own workspace arena) on the same device, with this context's options; options set
+        on this context later are applied to its clones too (a lane must blend the way its pipeline was told to)."""
+        import weakref
+        c = DeviceContext(self.device_index)
+        for name, value in self.options.items():
+            c.set_option(name, value)
+        self._clones.append(weakref.ref(c))
+        return c
 
-    def new_stream(self, priority=0):
-        """A new stream; priority -1 = served before the default-priority streams by the hardware dispatcher."""
-        return torch.cuda.Stream(self.device, priority=priority)
+    def new_stream(self):
+        """A new stream of the default priority (the library refuses any other: gs_ctx_set_stream)."""
+        return torch.cuda.Stream(self.device)
 
     def current_stream(self):
         return torch.cuda.current_stream(self.device)
@@ -84,7 +92,21 @@ class DeviceContext:
 
     def set_option(self, name, value):
         check(self.lib.gs_ctx_set_option(self.handle, name.encode(), int(value)), "gs_ctx_set_option")
-        self.options = dict(getattr(self, "options", {}), **{name: int(value)})
+        self.options = dict(self.options, **{name: int(value)})
+        alive = []
+        for ref in self._clones:
+            c = ref()
+            if c is not None and c.handle:
+                c.set_option(name, value)
+                alive.append(ref)
+        self._clones = alive
+
+    def info(self, name):
+        """gs_ctx_info: "workspace_bytes" or "allocations" of this context's arena."""
+        v = int(self.lib.gs_ctx_info(self.handle, name.encode()))
+        if v < 0:
+            raise GsError(f"gs_ctx_info: unknown name '{name}'")
+        return v
 
     def profile(self, enable=True):
         """Bracket every kernel launch with HIP events (see read_profile)."""
@@ -378,8 +400,23 @@ def bin_culled_begin(ctx, tiles_touched, depths, result_size, tile_size, cull):
     return dict(c=c, N=N, rect=rect, dep=dep, held=held, extra=extra, W=W, H=H, ts=ts, off=float(off))
 
 
+def bin_exact_begin(ctx, tiles_touched, depths, result_size, tile_size):
+    """First half of match_gaus_to_tiles on the reference's own lists (gs_bin_count_begin): launches the count
+    and returns a token for bin_culled_finish; the host does not wait."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    dev = c.device
+    N = len(depths)
+    rect = _dev(tiles_touched, torch.int32, dev, (N, 4))
+    dep = _dev(depths, torch.int32, dev, (N,))
+    W, H, ts = int(result_size[0]), int(result_size[1]), int(tile_size)
+    check(c.lib.gs_bin_count_begin(c.handle, N, _ptr(rect), _ptr(dep), W, H, ts), "gs_bin_count_begin")
+    return dict(c=c, N=N, rect=rect, dep=dep, held=(), extra=None, W=W, H=H, ts=ts, off=0.0)
+
+
 def bin_culled_finish(tok, want_keys=False):
-    """Second half: waits for the count only (gs_bin_count_end), then sorts (gs_bin_fill_culled)."""
+    """Second half: waits for the count only (gs_bin_count_end), then sorts (gs_bin_fill_culled, or gs_bin_fill
+    for a token of bin_exact_begin)."""
     c = tok["c"]
     c.sync_stream()
     dev = c.device
@@ -390,8 +427,13 @@ def bin_culled_finish(tok, want_keys=False):
     keys = torch.empty((max(D.value, 1),), dtype=torch.int64, device=dev) if want_keys else None
     vals = torch.empty((max(D.value, 1),), dtype=torch.int32, device=dev)
     ranges = torch.empty((tiles, 2), dtype=torch.int32, device=dev)
-    check(c.lib.gs_bin_fill_culled(c.handle, N, _ptr(tok["rect"]), _ptr(tok["dep"]), *tok["extra"], W, H, ts,
-                                   tok["off"], D.value, _ptr(keys), _ptr(vals), _ptr(ranges)), "gs_bin_fill_culled")
+    if tok["extra"] is None:
+        check(c.lib.gs_bin_fill(c.handle, N, _ptr(tok["rect"]), _ptr(tok["dep"]), W, H, ts, D.value, _ptr(keys),
+                                _ptr(vals), _ptr(ranges)), "gs_bin_fill")
+    else:
+        check(c.lib.gs_bin_fill_culled(c.handle, N, _ptr(tok["rect"]), _ptr(tok["dep"]), *tok["extra"], W, H, ts,
+                                       tok["off"], D.value, _ptr(keys), _ptr(vals), _ptr(ranges)),
+              "gs_bin_fill_culled")
     return TileBinning(keys[:D.value] if want_keys else None, vals[:D.value], ranges, D.value, [W, H], ts)
 
 

@@ -238,7 +238,7 @@ extern "C" int gs_bin_bounds_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
     GS_HIP(hipGetLastError());
     GS_HIP(hipMemcpyAsync(ctx->total_host + 2, out, (size_t)n_views * 16, hipMemcpyDeviceToHost, ctx->stream));
     GS_HIP(hipEventRecord(ctx->bounds_event, ctx->stream));
-    GS_HIP(hipEventSynchronize(ctx->bounds_event));
+    if ((rc = gs_wait_event(ctx, ctx->bounds_event, "gs_bin_bounds_batch"))) return rc;
     for (int v = 0; v < n_views; v++) {
         const uint64_t pairs = ctx->total_host[2 + 2 * v];
         if (pairs >= (1ull << 31))
@@ -264,8 +264,16 @@ extern "C" int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
         GS_REQUIRE(capacity == 0 || views[v].vals, "gs_bin_culled_batch: view %d has a NULL vals", v);
         GS_REQUIRE(((uintptr_t)views[v].records & 15) == 0, "gs_bin_culled_batch: records must be 16-byte aligned");
     }
+    // the batch overwrites the per-view workspace (counts, offsets, depth order, totals): a pending
+    // gs_bin_count*_begin would be answered from another view's numbers, and a later gs_bin_fill* must not pass
+    // its state check against what an earlier gs_bin_count left behind
+    if (ctx->count_pending_N >= 0)
+        return gs_set_error(GS_ERR_STATE, "gs_bin_culled_batch: a gs_bin_count*_begin is pending on this ctx "
+                            "(call gs_bin_count_end first, or use another ctx)");
     GS_HIP(hipSetDevice(ctx->device));
     ctx->packed_fresh = false;
+    ctx->bin_N = -1;
+    ctx->bin_D = -1;
     const int nv = n_views;
     const Grid grid{gs_div_up(res_w, tile_size), gs_div_up(res_h, tile_size)};
     const int tiles = grid.tiles_x * grid.tiles_y;

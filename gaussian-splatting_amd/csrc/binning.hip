@@ -342,7 +342,7 @@ int bin_count_end(gs_ctx *ctx, int64_t *D_host) {
         ctx->bin_D = 0;
         return GS_OK;
     }
-    GS_HIP(hipEventSynchronize(ctx->count_event));
+    if (const int rc = gs_wait_event(ctx, ctx->count_event, "gs_bin_count_end")) return rc;
     const uint64_t D = ctx->total_host[0];
     if (D >= (1ull << 31))
         return gs_set_error(GS_ERR_ARG, "gs_bin_count: %llu duplicates exceed the 2^31-1 limit",
@@ -477,6 +477,13 @@ extern "C" int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched
     GS_REQUIRE(D_host, "gs_bin_count: D_host is NULL");
     if ((rc = bin_count_begin(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, nullptr, 0.0f))) return rc;
     return bin_count_end(ctx, D_host);
+}
+
+extern "C" int gs_bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                                  int32_t res_w, int32_t res_h, int32_t tile_size) {
+    int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
+    if (rc) return rc;
+    return bin_count_begin(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, nullptr, 0.0f);
 }
 
 extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,

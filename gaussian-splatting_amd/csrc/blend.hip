@@ -16,6 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int tiles_
 // Deterministic backward, stage 2: the list positions sorted by gaussian id (stable, so ascending inside a run).
 // One 16-lane group per sorted element; the group at the head of a gaussian's run walks the run and adds the
 // partials of every sub-block in that fixed order, lanes 0..8 one component each, then stores the row.
-__global__ __launch_bounds__(256) void det_reduce_kernel(int64_t D, int nsub, const uint32_t *__restrict__ gid_sorted,
+__global__ __launch_bounds__(256) void det_reduce_kernel(int64_t D, int nsub, uint32_t N, const uint32_t *__restrict__ gid_sorted,
                                                          const int32_t *__restrict__ pos_sorted,
                                                          const float *__restrict__ det, float *__restrict__ grad_rows) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -880,7 +881,9 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(int64_t D, int nsub, co
     if (i >= D) return;
     const uint32_t g = gid_sorted[i];
     if (i > 0 && gid_sorted[i - 1] == g) return;      // not the head of its run
-    if (comp >= 9) return;
+    // ids beyond N are not gaussians: a list handed over with D = its capacity (gs_bin_culled_batch) has an
+    // unwritten tail behind the last tile's range; nothing of it may become a store address
+    if (comp >= 9 || g >= N) return;
     float sum = 0.0f;
     for (int64_t j = i; j < D && gid_sorted[j] == g; j++) {
         const int64_t pos = pos_sorted[j];
@@ -1052,7 +1055,7 @@ int blend_backward_deterministic(gs_ctx *ctx, const QuadArgs &q, const BlendArgs
         return rc;
     const int64_t threads = D * 16;
     hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, D, nsub,
-                       k_sorted, p_sorted, (const float *)det, rows);
+                       (uint32_t)N, k_sorted, p_sorted, (const float *)det, rows);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -1143,9 +1146,12 @@ static __device__ __align__(256) float4 scratch[(size_t)GS_NOALLOC_MAX_N * 8];
 constexpr int GS_MAX_DEVICES = 64;
 static float4 *g_scratch_ptr[GS_MAX_DEVICES];     // per device: address of that GPU's copy of `scratch`
 
+static std::mutex g_scratch_lock;                // contexts may be created from several host threads
+
 int gs_scratch_setup(int device) {                // the device must be current
     if (device < 0 || device >= GS_MAX_DEVICES)
         return gs_set_error(GS_ERR_ARG, "gs_scratch_setup: device %d out of range (max %d)", device, GS_MAX_DEVICES);
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
     if (g_scratch_ptr[device]) return GS_OK;
     void *p = nullptr;
     GS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));

@@ -88,9 +88,15 @@ struct gs_ctx {
     int32_t ext_records_N = -1;
     bool packed_fresh = false;   // gs_bin_fill_culled packed them: the next gs_blend_forward may reuse them
     bool bin_culled = false;     // gs_bin_count_culled produced bin_N / bin_D
+    std::vector<hipStream_t> checked_streams;   // streams whose priority has been checked (gs_ctx_set_stream)
+    double wait_limit_ms = 30000.0;   // longest host wait for an event before the call reports an error
+    size_t workspace_bytes = 0;       // bytes held by the gs_bufs of this ctx
+    int64_t allocations = 0;          // hipMallocs made by gs_buf_reserve since the ctx was created
 };
 
 int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);
+// ctx.hip: bounded host wait for an event (error instead of a hang when the stream never gets there)
+int gs_wait_event(gs_ctx *ctx, hipEvent_t ev, const char *what);
 // blend.hip: looks up this device's copy of the static scratch array (gs_blend_backward_noalloc); device must be current
 int gs_scratch_setup(int device);
 // binning.hip: stable LSD radix sort of n (u32 key, i32 value) pairs on the low `bits` bits; values start as 0..n-1

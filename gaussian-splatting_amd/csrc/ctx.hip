@@ -6,6 +6,8 @@ static_assert(sizeof(gs_camera) == 144, "gs_camera layout is part of the C ABI (
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <thread>
 
 static thread_local char g_err[512] = "";
 
@@ -25,12 +27,51 @@ int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes) {
     // the old block may still be in use by work queued on the stream
     GS_HIP(hipStreamSynchronize(ctx->stream));
     if (b->p) GS_HIP(hipFree(b->p));
+    ctx->workspace_bytes -= b->cap;
     b->p = nullptr;
     b->cap = 0;
     size_t want = bytes + bytes / 4 + 256;
     GS_HIP(hipMalloc(&b->p, want));
     b->cap = want;
+    ctx->workspace_bytes += want;
+    ctx->allocations++;      // gs_ctx_info("allocations"): a caller that reserved ahead checks that a step adds none
     return GS_OK;
+}
+
+// The library's streams: default priority only.  Round 2 measured a scheduler that put the list kernels on a
+// high-priority stream in front of default-priority blend streams, with events between them: a later
+// gs_bin_count_end never returned (DESIGN.md, section Concurrency).  The cause was not established beyond that
+// arrangement, so it is refused at the boundary instead of being offered.
+static int check_stream_priority(gs_ctx *ctx, hipStream_t stream) {
+    for (hipStream_t s : ctx->checked_streams)
+        if (s == stream) return GS_OK;
+    int prio = 0;
+    GS_HIP(hipStreamGetPriority(stream, &prio));
+    GS_REQUIRE(prio == 0, "stream %p has priority %d: the library launches on default-priority streams only "
+               "(priority streams with cross-stream event waits hung the GPU, DESIGN.md section Concurrency)",
+               (void *)stream, prio);
+    if (ctx->checked_streams.size() < 64) ctx->checked_streams.push_back(stream);
+    return GS_OK;
+}
+
+// Host wait for `ev` that cannot hang the process: polls until the event has completed or limit_ms have
+// passed (GSPLAT_WAIT_TIMEOUT_MS, default 30 s), then reports an error.  The first 200 us spin (a tile count is
+// on the host within that), later polls yield the core.
+int gs_wait_event(gs_ctx *ctx, hipEvent_t ev, const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; spins++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return GS_OK;
+        if (e != hipErrorNotReady)
+            return gs_set_error(GS_ERR_HIP, "%s: hipEventQuery failed: %s", what, hipGetErrorString(e));
+        if ((spins & 15) == 15) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > ctx->wait_limit_ms)
+                return gs_set_error(GS_ERR_HIP, "%s: the device has not finished after %.0f ms (GSPLAT_WAIT_TIMEOUT_MS); the "
+                                    "stream is stuck behind work that does not complete", what, ms);
+            if (ms > 0.2) std::this_thread::yield();
+        }
+    }
 }
 
 extern "C" int gs_ctx_create(int device, void *stream, gs_ctx **out) {
@@ -47,6 +88,14 @@ extern "C" int gs_ctx_create(int device, void *stream, gs_ctx **out) {
     gs_ctx *c = new gs_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;
+    if (const int rc = check_stream_priority(c, c->stream)) {
+        delete c;
+        return rc;
+    }
+    if (const char *e = getenv("GSPLAT_WAIT_TIMEOUT_MS")) {
+        const double v = atof(e);
+        if (v > 0) c->wait_limit_ms = v;
+    }
     hipError_t e = hipHostMalloc((void **)&c->total_host, (2 + 2 * GS_BIN_MAX_VIEWS) * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         delete c;
@@ -145,8 +194,16 @@ extern "C" int gs_ctx_profile_read(gs_ctx *ctx, double *ms_sum, int64_t *launche
 
 extern "C" int gs_ctx_set_stream(gs_ctx *ctx, void *stream) {
     GS_REQUIRE(ctx != nullptr, "gs_ctx_set_stream: ctx is NULL");
+    if (const int rc = check_stream_priority(ctx, (hipStream_t)stream)) return rc;
     ctx->stream = (hipStream_t)stream;
     return GS_OK;
+}
+
+extern "C" int64_t gs_ctx_info(gs_ctx *ctx, const char *name) {
+    if (!ctx || !name) return -1;
+    if (strcmp(name, "workspace_bytes") == 0) return (int64_t)ctx->workspace_bytes;
+    if (strcmp(name, "allocations") == 0) return ctx->allocations;
+    return -1;
 }
 
 extern "C" int gs_ctx_use_records(gs_ctx *ctx, int32_t N, const float *records) {

@@ -11,7 +11,7 @@ are seeded, so every rank applies identical changes."""
 import torch
 
 from . import api
-from .pipeline import GROUP_WIDTHS, flat_offsets
+from .pipeline import GROUP_WIDTHS, all_reduce_sum, flat_offsets
 
 
 class Densifier:
@@ -54,8 +54,7 @@ class Densifier:
         import torch.distributed as dist
         p = self.pipe
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grad_accum)
-            dist.all_reduce(self.denom)
+            all_reduce_sum(p.ctx, [self.grad_accum, self.denom])
         avg = self.grad_accum / self.denom.clamp(min=1.0)
         hot = avg >= self.grad_threshold
         big = self._activated_scales().max(dim=1).values > self.percent_dense * self.scene_extent

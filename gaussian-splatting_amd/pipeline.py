@@ -130,12 +130,12 @@ class SplatPipeline:
 
     def preprocess_batch(self, views, ctx=None, records=None):
         """K1 for several views in one pass over the parameters; returns one record per view to hand to
-        forward(view, pre=...).  records=True (default when tiles are culled): gs_preprocess_batch_records
+        forward(view, pre=...).  records=True (default): gs_preprocess_batch_records
         writes each view's 64-byte blend records instead of centers / colors / conics, so no pack pass
         runs per view (the per-view arrays are then None)."""
         c = ctx or self.ctx
         c.sync_stream()
-        records = self.cull_tiles if records is None else bool(records)
+        records = True if records is None else bool(records)   # the blend kernels read records on either list kind
         opac = torch.sigmoid(self.opacity) if self.opacity_is_logit else self.opacity   # once for the batch
         cams = [api.make_camera(v.camera, v.camera_r, v.camera_t, self.result_size, self.tile_size, self.degrees,
                                  self.cam_flags)
@@ -199,6 +199,9 @@ class SplatPipeline:
                 tok["bin"] = api.bin_culled_begin(c, pre["rect"], pre["depths"], self.result_size, self.tile_size,
                                                   (pre["centers"], pre["colors"], opac, pre["conics"],
                                                    self.pixel_offset))
+        else:
+            # the reference's own lists (bit-exact keys and ranges): same two halves, no box test
+            tok["bin"] = api.bin_exact_begin(c, pre["rect"], pre["depths"], self.result_size, self.tile_size)
         return tok
 
     def forward_finish(self, tok, want_keys=False, after_blend=None):
@@ -218,11 +221,7 @@ class SplatPipeline:
         # the records are a per-call binding: whatever raises in between (D >= 2^31, out of memory), the ctx
         # does not keep a pointer to tensors this call owns
         with _records(c, self.N, pre.get("rec")):
-            if tok["bin"] is not None:
-                tok["binning"] = api.bin_culled_finish(tok["bin"], want_keys=want_keys)
-            else:
-                tok["binning"] = api.match_gaus_to_tiles(c, None, None, pre["rect"], pre["radii"], pre["depths"],
-                                                         self.result_size, self.tile_size, want_keys=want_keys)
+            tok["binning"] = api.bin_culled_finish(tok["bin"], want_keys=want_keys)
         return tok["binning"]
 
     def forward_blend(self, tok, ctx=None):
@@ -438,23 +437,29 @@ def gaussian_chunks(N, n_chunks):
     return [(g0, min(g0 + step, N)) for g0 in range(0, N, step)] or [(0, 0)]
 
 
-def _all_reduce(pipe, tensors, works):
-    """SUM all-reduce of every tensor in `tensors` over the default process group.  RCCL ("nccl"): the
-    collectives are stream-ordered behind what the current stream holds and run on the communicator's own
-    stream, so they are issued asynchronously and `works` collects their handles (wait on them before the
-    gradients are used): later kernels on the current stream overlap them.  Host-staged back ends (gloo):
-    issued on an idle device and blocking.  Measured on MI355X with two ranks sharing one GPU: a gloo
-    all-reduce of a device tensor issued while the rank's lane streams still held work never completed
-    (the same collective alone, or behind a device synchronisation, completes in 135 ms for 236 MB)."""
+def all_reduce_sum(ctx, tensors, works=None):
+    """SUM all-reduce of every tensor in `tensors` over the default process group -- the ONE place the package
+    issues a collective.  RCCL ("nccl"): stream-ordered behind what the current stream holds and run on the
+    communicator's own stream; with a `works` list they are issued asynchronously and the handles appended (wait on
+    them before the result is used), otherwise the call blocks the stream as usual.  Host-staged back ends (gloo):
+    always behind a device synchronisation and blocking -- measured on MI355X with two ranks sharing one GPU, a
+    gloo all-reduce of a device tensor issued while the rank's lane streams still held work never completed (the
+    same collective alone, or behind a synchronisation, completes in 135 ms for 236 MB)."""
     import torch.distributed as dist
     if dist.get_backend() == "nccl":
         for t in tensors:
-            works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=works is not None)
+            if works is not None:
+                works.append(w)
         return
-    if tensors and tensors[0].device.type != "cpu":
-        pipe.ctx.synchronize()
+    if any(t.device.type != "cpu" for t in tensors):
+        ctx.synchronize()
     for t in tensors:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def _all_reduce(pipe, tensors, works):
+    all_reduce_sum(pipe.ctx, tensors, works)
 
 
 def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,

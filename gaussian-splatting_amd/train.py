@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import io as gio
-from .pipeline import FlatGrads, Optimizer, SplatPipeline, View, train_step
+from .pipeline import FlatGrads, Optimizer, SplatPipeline, View, all_reduce_sum, train_step
 
 
 def default_image_loader(image_dir, result_size):
@@ -95,7 +95,7 @@ def train_model(cameras, images, point_cloud_data, learning_rates, ctx=None, que
             # method="reference" scales it by the loss, so the loss is the mean over the WHOLE batch
             both = torch.stack([loss_sum.reshape(()).to(torch.float32),
                                 torch.tensor(float(n_local), dtype=torch.float32, device=loss_sum.device)])
-            dist.all_reduce(both, op=dist.ReduceOp.SUM)
+            all_reduce_sum(pipe.ctx, [both])      # behind a device synchronisation on host-staged back ends
             mean_loss = float(both[0].item()) / max(float(both[1].item()), 1.0)
         else:
             mean_loss = float(loss_sum.item()) / max(n_local, 1)

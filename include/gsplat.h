@@ -50,8 +50,14 @@ typedef struct gs_camera {
 /* Replaces setup_gpu() (setup_gpu.py:3-6,370): device context = device id + stream + workspace
  * arena. `stream` is a hipStream_t (NULL = default stream). */
 int gs_ctx_create(int device, void *stream, gs_ctx **out);
+/* The stream must have the DEFAULT priority (hipStreamGetPriority == 0): anything else is refused with an error.
+ * (No reference counterpart: the reference has one OpenCL queue, setup_gpu.py:4-5.) */
 int gs_ctx_set_stream(gs_ctx *ctx, void *stream);
 int gs_ctx_destroy(gs_ctx *ctx);
+/* Workspace accounting (no reference counterpart): name "workspace_bytes" = device bytes the ctx holds,
+ * "allocations" = hipMallocs it has made since it was created (a grow-only arena: a training loop that
+ * reserved ahead checks that a step adds none).  Returns -1 for an unknown name. */
+int64_t gs_ctx_info(gs_ctx *ctx, const char *name);
 /* Tuning knobs (no reference counterpart).  "pixels_per_thread": 1, 2 or 4 pixels of a tile
  * column per thread in the blend kernels (default 4 = one wavefront per 16x16 tile; also read
  * from the environment variable GSPLAT_PPT at ctx creation).
@@ -169,6 +175,11 @@ int gs_bin_count_culled_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touch
                               const float *centers, const float *colors, const float *opacities,
                               const float *conics, int32_t res_w, int32_t res_h, int32_t tile_size,
                               float pixel_offset);
+/* the same first half for the reference's own lists (gs_bin_count = gs_bin_count_begin + gs_bin_count_end) */
+int gs_bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                       int32_t res_w, int32_t res_h, int32_t tile_size);
+/* The host wait is bounded: if the count has not completed after GSPLAT_WAIT_TIMEOUT_MS (environment, default
+ * 30000) the call returns an error instead of blocking for ever. */
 int gs_bin_count_end(gs_ctx *ctx, int64_t *D_host);
 
 /* The culled lists of up to GS_BIN_MAX_VIEWS views per call, built by launches that each cover every view of the

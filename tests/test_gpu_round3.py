@@ -1,0 +1,189 @@
+"""Round-3 robustness tests on the GPU, all through the C ABI: context options reach every lane, the batched
+binning call guards the per-view state, the ordered K7 reduction is safe on capacity-sized lists, priority
+streams are refused, the event wait is bounded, workspace accounting."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import synth_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(gs, cam, R, n):
+    return [gs.View(cam, R, np.array([0.05 * k, -0.02 * k, 0.1 * k])) for k in range(n)]
+
+
+def test_deterministic_backward_holds_on_every_lane_of_a_step(gpu_ctx):
+    """deterministic_backward set on the pipeline's ctx must reach the lane and alternate contexts (clones): two
+    4-lane steps give bit-identical gradients, whether the option is set before the lanes exist or after."""
+    import torch
+    import gsplat_amd as gs
+    W, H = 320, 240
+    cam, R, t, g, rs = synth_scene(6000, W, H, seed=41, fx=200.0, log_scale=(1.5, 3.2))
+    views = _views(gs, cam, R, 6)
+    gen = torch.Generator(device="cpu").manual_seed(41)
+    targets = [torch.rand(W, H, 3, generator=gen).to(gpu_ctx.device) for _ in views]
+
+    def step(pipe):
+        grads = gs.FlatGrads(pipe.N, gpu_ctx.device)
+        gs.train_step(pipe, views, targets, grads, concurrent_views=4)
+        torch.cuda.synchronize()
+        return grads.flat.clone()
+
+    # (a) lanes created first (atomics), option set afterwards: set_option must reach the existing clones
+    late = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    ref = step(late)
+    gpu_ctx.set_option("deterministic_backward", 1)
+    try:
+        for c in late.contexts():
+            assert c.options.get("deterministic_backward") == 1
+        a, b = step(late), step(late)
+        assert torch.equal(a, b)
+        # (b) a pipeline whose lanes are cloned while the option is already on
+        early = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+        c = step(early)
+        assert all(x.options.get("deterministic_backward") == 1 for x in early.contexts())
+        assert torch.equal(a, c)
+    finally:
+        gpu_ctx.set_option("deterministic_backward", 0)
+    assert all(x.options.get("deterministic_backward") == 0 for x in late.contexts())
+    scale = float(ref.abs().max())
+    assert float((a - ref).abs().max()) <= 2e-5 * scale      # the atomics form agrees to rounding
+
+
+def test_batched_binning_guards_the_per_view_state(gpu_ctx):
+    """gs_bin_culled_batch overwrites the ctx's per-view workspace: it refuses to run over a pending
+    gs_bin_count*_begin, and a gs_bin_fill* after it must not pass the state check of an older count."""
+    import gsplat_amd as gs
+    from bench import make_views
+    cam, R, t, g, rs = synth_scene(4000, 256, 192, seed=5, log_scale=(1.0, 3.0))
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    views = make_views(gs, cam, 2)
+    pres = pipe.preprocess_batch(views, records=True)
+    tok = pipe.forward_begin(views[0], pre=pres[0])                 # a count is now pending on gpu_ctx
+    with pytest.raises(gs.GsError, match="pending"):
+        gs.api.bin_culled_batch(gpu_ctx, pres, rs, 16, pipe.pixel_offset)
+    first = pipe.forward_bin(tok)                                   # the pending count is still answered correctly
+    D = first.D
+    batch = gs.api.bin_culled_batch(gpu_ctx, pres, rs, 16, pipe.pixel_offset)
+    assert batch[0].true_D() == D
+    # a fill with the OLD (N, D) must be refused now: the workspace holds the batch's numbers
+    import torch
+    vals = torch.empty(D, dtype=torch.int32, device=gpu_ctx.device)
+    ranges = torch.empty((first.ranges.shape[0], 2), dtype=torch.int32, device=gpu_ctx.device)
+    p = pres[0]
+    with pipe_records(gs, gpu_ctx, pipe.N, p["rec"]):
+        rc = gpu_ctx.lib.gs_bin_fill_culled(gpu_ctx.handle, pipe.N, gs.api._ptr(p["rect"]), gs.api._ptr(p["depths"]),
+                                            None, None, None, None, rs[0], rs[1], 16, 0.5, D, None,
+                                            gs.api._ptr(vals), gs.api._ptr(ranges))
+    assert rc == -3          # GS_ERR_STATE
+
+
+class pipe_records:
+    def __init__(self, gs, c, N, rec):
+        self.gs, self.c, self.N, self.rec = gs, c, N, rec
+
+    def __enter__(self):
+        assert self.c.lib.gs_ctx_use_records(self.c.handle, self.N, self.gs.api._ptr(self.rec)) == 0
+
+    def __exit__(self, *exc):
+        self.c.lib.gs_ctx_use_records(self.c.handle, 0, None)
+        return False
+
+
+def test_ordered_reduction_is_safe_on_capacity_sized_lists(gpu_ctx):
+    """A list from gs_bin_culled_batch is handed to the blend calls with D = its capacity; the tail behind the last
+    range is unwritten memory.  With deterministic_backward the entries are sorted by gaussian id: ids beyond N must
+    never become a store address, and the gradients equal those of the per-view list bit for bit."""
+    import torch
+    import gsplat_amd as gs
+    from bench import make_views
+    W, H = 256, 192
+    cam, R, t, g, rs = synth_scene(5000, W, H, seed=8, log_scale=(1.0, 3.0))
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    views = make_views(gs, cam, 1)
+    pres = pipe.preprocess_batch(views, records=True)
+    tok = pipe.forward_begin(views[0], pre=pres[0])
+    ref = pipe.forward_bin(tok)
+    cap = ref.D + 5000
+    b = gs.api.bin_culled_batch(gpu_ctx, pres, rs, 16, pipe.pixel_offset, depth_bits=32, capacity=cap)[0]
+    b.vals[ref.D:] = torch.randint(-2 ** 31, 2 ** 31 - 1, (cap - ref.D,), dtype=torch.int64,
+                                   device=gpu_ctx.device).to(torch.int32)     # hostile tail
+    dL = torch.rand(W, H, 3, generator=torch.Generator().manual_seed(1)).to(gpu_ctx.device)
+    guard = torch.full((4096,), 7.0, device=gpu_ctx.device)       # allocated right after the rows below
+    gpu_ctx.set_option("deterministic_backward", 1)
+    try:
+        rows = {}
+        for name, binning in (("ref", ref), ("cap", b)):
+            _, st = pipe.forward_blend(dict(pre=pres[0], opac=tok["opac"], binning=binning, c=gpu_ctx))
+            rows[name] = pipe.backward_rows(st, dL).clone()
+    finally:
+        gpu_ctx.set_option("deterministic_backward", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(rows["ref"], rows["cap"])
+    assert float(rows["ref"].abs().max()) > 0 and bool((guard == 7.0).all())
+
+
+def test_priority_streams_are_refused(gpu_ctx):
+    """The library launches on default-priority streams only (Concurrency): gs_ctx_set_stream reports an
+    error for any other, and the context keeps its previous stream."""
+    import torch
+    import gsplat_amd as gs
+    hi = torch.cuda.Stream(gpu_ctx.device, priority=-1)
+    rc = gpu_ctx.lib.gs_ctx_set_stream(gpu_ctx.handle, ctypes.c_void_p(hi.cuda_stream))
+    assert rc == -1 and b"priority" in gpu_ctx.lib.gs_last_error()
+    with pytest.raises(gs.GsError, match="priority"):
+        with gpu_ctx.use_stream(hi):
+            gpu_ctx.sync_stream()
+    gpu_ctx.sync_stream()
+    cam, R, t, g, rs = synth_scene(500, 64, 48, seed=2, fx=60.0)
+    image, _ = gs.SplatPipeline(g, rs, ctx=gpu_ctx).forward(gs.View(cam, R, t))
+    assert bool(torch.isfinite(image).all())
+    import inspect
+    assert "priority" not in inspect.signature(gpu_ctx.new_stream).parameters
+
+
+def test_count_wait_is_bounded(gpu_ctx):
+    """gs_bin_count_end gives up with an error when the count does not complete in time (GSPLAT_WAIT_TIMEOUT_MS)
+    instead of blocking for ever: a stream held back by 0.3 s of queued work stands in for a stuck one."""
+    import os
+    import torch
+    import gsplat_amd as gs
+    os.environ["GSPLAT_WAIT_TIMEOUT_MS"] = "20"
+    try:
+        c = gs.DeviceContext(gpu_ctx.device_index)
+    finally:
+        del os.environ["GSPLAT_WAIT_TIMEOUT_MS"]
+    cam, R, t, g, rs = synth_scene(2000, 128, 96, seed=3, fx=100.0)
+    pipe = gs.SplatPipeline(g, rs, ctx=c)
+    s = c.new_stream()
+    with c.use_stream(s):
+        pipe.forward(gs.View(cam, R, t))               # sizes the workspace (a first call allocates, which synchronises)
+        x = torch.zeros(2 ** 28, dtype=torch.float32, device=c.device)
+        for _ in range(600):                           # ~0.3 s of device time in front of the count
+            x.add_(1.0)
+        tok = pipe.forward_begin(gs.View(cam, R, t))
+        with pytest.raises(gs.GsError, match="has not finished"):
+            pipe.forward_bin(tok)
+    torch.cuda.synchronize()
+    image, _ = pipe.forward(gs.View(cam, R, t))         # the context is usable afterwards
+    assert bool(torch.isfinite(image).all())
+    c.close()
+
+
+def test_workspace_accounting(gpu_ctx):
+    import gsplat_amd as gs
+    c = gs.DeviceContext(gpu_ctx.device_index)
+    assert c.info("workspace_bytes") == 0 and c.info("allocations") == 0
+    cam, R, t, g, rs = synth_scene(3000, 128, 96, seed=3, fx=100.0)
+    pipe = gs.SplatPipeline(g, rs, ctx=c)
+    pipe.forward(gs.View(cam, R, t))
+    a1, b1 = c.info("allocations"), c.info("workspace_bytes")
+    assert a1 > 0 and b1 > 0
+    pipe.forward(gs.View(cam, R, t))
+    assert c.info("allocations") == a1 and c.info("workspace_bytes") == b1     # steady state: no hipMalloc
+    with pytest.raises(gs.GsError):
+        c.info("nonsense")
+    c.close()

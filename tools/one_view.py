@@ -1,5 +1,6 @@
 """A few forward+backward views of the bench scene on ONE stream (for rocprofv3 --pmc passes, where
-per-kernel counters must not overlap).  GS_VIEWS views, then one batched parameter backward."""
+per-kernel counters must not overlap).  GS_VIEWS views, then one batched parameter backward.  GS_LISTS = exact
+(default, bench.py's default) or culled."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import importlib
@@ -14,7 +15,8 @@ N = int(os.environ.get("GS_N", 1_000_000))
 W, H = 1920, 1080
 g, cam = make_scene(N, W, H, (1.0, 3.0))
 ctx, _, _ = gs.setup_gpu(0)
-pipe = gs.SplatPipeline(g, [W, H], ctx=ctx)
+LISTS = os.environ.get("GS_LISTS", "exact")     # bench.py's default: the reference's own lists
+pipe = gs.SplatPipeline(g, [W, H], ctx=ctx, cull_tiles=LISTS == "culled")
 views = make_views(gs, cam, 8)
 grads = gs.FlatGrads(N, ctx.device)
 target = torch.rand(W, H, 3, device=ctx.device)
