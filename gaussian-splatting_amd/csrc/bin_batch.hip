@@ -9,7 +9,7 @@
 //                         depth key; ONE host wait for the whole batch
 //   gs_bin_culled_batch   count -> depth sort -> scan -> emit -> tile sort -> ranges for every view of the batch,
 //                         about 20 launches in all, no host wait; D stays in device memory
-#include "binning_kernels.h"
+#include "radix_sort.h"
 
 namespace {
 
@@ -85,15 +85,14 @@ struct PairsArgs {
     const int32_t *perm[BIN_MAX_VIEWS];
     uint32_t *counts[BIN_MAX_VIEWS];
     const uint32_t *offsets[BIN_MAX_VIEWS];
-    uint32_t *tile_keys[BIN_MAX_VIEWS];
-    int32_t *vals[BIN_MAX_VIEWS];
+    uint2 *pairs[BIN_MAX_VIEWS];
 };
 
 template <bool EMIT>
 __global__ __launch_bounds__(256) void pairs_batch_kernel(PairsArgs a, int N, Grid grid, CullBox cb, uint32_t cap) {
     const int v = blockIdx.y;
     culled_pairs_body<EMIT>(blockIdx.x, N, a.perm[v], a.rect[v], a.depth[v], grid, a.rec[v], cb, a.counts[v],
-                            a.offsets[v], cap, a.tile_keys[v], a.vals[v]);
+                            a.offsets[v], cap, a.pairs[v]);
 }
 
 struct ScanArgs {
@@ -118,32 +117,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void offsets_batch_kernel(ScanArgs a,
 }
 
 struct RadixArgs {
-    const uint32_t *keys_in[BIN_MAX_VIEWS];
-    const int32_t *vals_in[BIN_MAX_VIEWS];
-    uint32_t *keys_out[BIN_MAX_VIEWS];
-    int32_t *vals_out[BIN_MAX_VIEWS];
+    RadixIO io[BIN_MAX_VIEWS];
     uint32_t *table[BIN_MAX_VIEWS];       // [256] digit totals, then [256][nblocks]
-    const uint32_t *n_dev[BIN_MAX_VIEWS]; // NULL: every view sorts n keys
-    uint32_t n;                           // with n_dev: the capacity (keys beyond it do not exist)
+    const uint32_t *n_dev[BIN_MAX_VIEWS]; // NULL: every view sorts n elements
+    uint32_t n;                           // with n_dev: the capacity (elements beyond it do not exist)
 };
 
 __device__ __forceinline__ uint32_t view_n(const RadixArgs &a, int v) {
     return a.n_dev[v] ? min(*a.n_dev[v], a.n) : a.n;
 }
 
+// the batch sorts with 4096-element workgroups whatever the capacity: a view's real count is only known on the device
+template <bool PAIRS>
 __global__ __launch_bounds__(RADIX_THREADS) void hist_batch_kernel(RadixArgs a, int shift, uint32_t mask, uint32_t nblocks) {
     const int v = blockIdx.y;
-    radix_hist_body(blockIdx.x, view_n(a, v), a.keys_in[v], shift, mask, nblocks, a.table[v] + RADIX_BINS);
+    radix2_hist_body<RADIX_THREADS, RADIX_ITEMS, PAIRS>(blockIdx.x, view_n(a, v), a.io[v].keys_in, a.io[v].pairs_in, shift, mask,
+                                                        nblocks, a.table[v] + RADIX_BINS);
 }
-__global__ __launch_bounds__(RADIX_THREADS) void rscan_batch_kernel(RadixArgs a, uint32_t nblocks) {
+__global__ __launch_bounds__(SCAN_THREADS) void rscan_batch_kernel(RadixArgs a, uint32_t nblocks) {
     const int v = blockIdx.y;
     radix_scan_body(blockIdx.x, nblocks, a.table[v] + RADIX_BINS, a.table[v]);
 }
-template <int NBITS>
+template <int NBITS, int MODE>
 __global__ __launch_bounds__(RADIX_THREADS) void scatter_batch_kernel(RadixArgs a, int shift, uint32_t mask, uint32_t nblocks) {
     const int v = blockIdx.y;
-    radix_scatter_body<NBITS>(blockIdx.x, view_n(a, v), a.keys_in[v], a.vals_in[v], a.keys_out[v], a.vals_out[v], shift,
-                              mask, nblocks, a.table[v] + RADIX_BINS, a.table[v]);
+    radix2_scatter_body<NBITS, RADIX_THREADS, RADIX_ITEMS, MODE>(blockIdx.x, view_n(a, v), a.io[v], shift, mask, nblocks,
+                                                                 a.table[v] + RADIX_BINS, a.table[v]);
 }
 
 struct RangesArgs {
@@ -167,21 +166,30 @@ __global__ __launch_bounds__(256) void ranges_batch_kernel(RangesArgs a) {
     }
 }
 
-int radix_pass_batch(gs_ctx *ctx, int nv, const RadixArgs &a, uint32_t n_upper, int shift, int nbits) {
-    const uint32_t nblocks = (n_upper + RADIX_TILE - 1) / RADIX_TILE;
+int radix_pass_batch(gs_ctx *ctx, int nv, const RadixArgs &a, uint32_t n_upper, int mode, int shift, int nbits) {
+    constexpr int TILE = RADIX_THREADS * RADIX_ITEMS;
+    const uint32_t nblocks = (n_upper + TILE - 1) / TILE;
     const uint32_t mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL(hist_batch_kernel, dim3(nblocks, nv), dim3(RADIX_THREADS), 0, ctx->stream, a, shift, mask, nblocks);
-    hipLaunchKernelGGL(rscan_batch_kernel, dim3(RADIX_BINS, nv), dim3(RADIX_THREADS), 0, ctx->stream, a, nblocks);
-#define GS_SCATTER(NB)                                                                                             \
-    case NB:                                                                                                       \
-        hipLaunchKernelGGL(scatter_batch_kernel<NB>, dim3(nblocks, nv), dim3(RADIX_THREADS), 0, ctx->stream, a, shift, \
-                           mask, nblocks);                                                                         \
+    if (mode == RADIX_SOA)
+        hipLaunchKernelGGL(hist_batch_kernel<false>, dim3(nblocks, nv), dim3(RADIX_THREADS), 0, ctx->stream, a, shift, mask, nblocks);
+    else
+        hipLaunchKernelGGL(hist_batch_kernel<true>, dim3(nblocks, nv), dim3(RADIX_THREADS), 0, ctx->stream, a, shift, mask, nblocks);
+    hipLaunchKernelGGL(rscan_batch_kernel, dim3(RADIX_BINS, nv), dim3(SCAN_THREADS), 0, ctx->stream, a, nblocks);
+#define GS_SCATTER_M(NB, M)                                                                                            \
+    hipLaunchKernelGGL((scatter_batch_kernel<NB, M>), dim3(nblocks, nv), dim3(RADIX_THREADS), 0, ctx->stream, a, shift, mask, \
+                       nblocks)
+#define GS_SCATTER(NB)                                                                     \
+    case NB:                                                                               \
+        if (mode == RADIX_SOA) GS_SCATTER_M(NB, RADIX_SOA);                                \
+        else if (mode == RADIX_PAIRS) GS_SCATTER_M(NB, RADIX_PAIRS);                       \
+        else GS_SCATTER_M(NB, RADIX_PAIRS_TO_SOA);                                         \
         break;
     switch (nbits) {
         GS_SCATTER(1) GS_SCATTER(2) GS_SCATTER(3) GS_SCATTER(4) GS_SCATTER(5) GS_SCATTER(6) GS_SCATTER(7) GS_SCATTER(8)
         default: return gs_set_error(GS_ERR_ARG, "radix_pass_batch: %d bits per pass", nbits);
     }
 #undef GS_SCATTER
+#undef GS_SCATTER_M
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -283,13 +291,13 @@ extern "C" int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
     const size_t n4 = ((size_t)(N > 0 ? N : 1) * 4 + 255) & ~(size_t)255, d4 = ((size_t)(cap > 0 ? cap : 1) * 4 + 255) & ~(size_t)255;
     const int scan_blocks = gs_div_up(N > 0 ? N : 1, SCAN_TILE);
     const size_t bs4 = ((size_t)scan_blocks * 4 + 255) & ~(size_t)255;
-    const uint32_t nb_max = (uint32_t)gs_div_up((int)((uint32_t)N > cap ? (uint32_t)N : cap), RADIX_TILE) + 1;
+    const uint32_t nb_max = (uint32_t)gs_div_up((int)((uint32_t)N > cap ? (uint32_t)N : cap), RADIX_THREADS * RADIX_ITEMS) + 1;
     const size_t tab4 = (((size_t)RADIX_BINS * nb_max + RADIX_BINS) * 4 + 255) & ~(size_t)255;
     if ((rc = gs_buf_reserve(ctx, &ctx->counts, nv * n4))) return rc;
     if ((rc = gs_buf_reserve(ctx, &ctx->offsets, nv * n4))) return rc;
     if ((rc = gs_buf_reserve(ctx, &ctx->block_sums, nv * bs4))) return rc;
     if ((rc = gs_buf_reserve(ctx, &ctx->depth_sort, nv * 4 * n4))) return rc;
-    if ((rc = gs_buf_reserve(ctx, &ctx->keys_tmp, nv * 2 * d4))) return rc;
+    if ((rc = gs_buf_reserve(ctx, &ctx->keys_tmp, nv * 4 * d4))) return rc;     // pairs ping-pong: 2 x cap x 8 bytes per view
     if ((rc = gs_buf_reserve(ctx, &ctx->vals_tmp, nv * d4))) return rc;
     if ((rc = gs_buf_reserve(ctx, &ctx->radix_table, nv * tab4))) return rc;
     if ((rc = gs_buf_reserve(ctx, &ctx->total, 16 + (size_t)BIN_MAX_VIEWS * 4))) return rc;
@@ -343,14 +351,14 @@ extern "C" int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
                 char *ds = at(ctx->depth_sort, v * 4 * n4);
                 uint32_t *dk[2] = {(uint32_t *)ds, (uint32_t *)(ds + n4)};
                 int32_t *dv[2] = {(int32_t *)(ds + 2 * n4), (int32_t *)(ds + 3 * n4)};
-                a.keys_in[v] = p == 0 ? reinterpret_cast<const uint32_t *>(views[v].depths) : dk[(p - 1) & 1];
-                a.vals_in[v] = p == 0 ? nullptr : dv[(p - 1) & 1];
-                a.keys_out[v] = last ? nullptr : dk[p & 1];
-                a.vals_out[v] = dv[p & 1];
+                a.io[v].keys_in = p == 0 ? reinterpret_cast<const uint32_t *>(views[v].depths) : dk[(p - 1) & 1];
+                a.io[v].vals_in = p == 0 ? nullptr : dv[(p - 1) & 1];
+                a.io[v].keys_out = last ? nullptr : dk[p & 1];
+                a.io[v].vals_out = dv[p & 1];
                 a.table[v] = (uint32_t *)at(ctx->radix_table, v * tab4);
                 perm[v] = dv[p & 1];
             }
-            if ((rc = radix_pass_batch(ctx, nv, a, (uint32_t)N, 8 * p, nbits))) return rc;
+            if ((rc = radix_pass_batch(ctx, nv, a, (uint32_t)N, RADIX_SOA, 8 * p, nbits))) return rc;
         }
     }
 
@@ -376,17 +384,14 @@ extern "C" int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
     if (tile_bits == 0) tile_bits = 1;
     const int tile_passes = (tile_bits + 7) / 8;
     const int bits_per_pass = (tile_bits + tile_passes - 1) / tile_passes;
-    int cur = (tile_passes & 1) ? 0 : 1;      // value buffers alternate so that the last pass writes the caller's array
-    uint32_t *tk[BIN_MAX_VIEWS][2];
-    int32_t *vb[BIN_MAX_VIEWS][2];
+    uint2 *pp[BIN_MAX_VIEWS][2];
+    uint32_t *sorted_tiles[BIN_MAX_VIEWS];
     for (int v = 0; v < nv; v++) {
-        tk[v][0] = (uint32_t *)at(ctx->keys_tmp, v * 2 * d4);
-        tk[v][1] = (uint32_t *)at(ctx->keys_tmp, v * 2 * d4 + d4);
-        vb[v][0] = (int32_t *)at(ctx->vals_tmp, v * d4);
-        vb[v][1] = views[v].vals;
+        pp[v][0] = (uint2 *)at(ctx->keys_tmp, v * 4 * d4);
+        pp[v][1] = (uint2 *)at(ctx->keys_tmp, v * 4 * d4 + 2 * d4);
+        sorted_tiles[v] = (uint32_t *)at(ctx->vals_tmp, v * d4);
         pa.perm[v] = perm[v];
-        pa.tile_keys[v] = tk[v][0];
-        pa.vals[v] = vb[v][cur];
+        pa.pairs[v] = pp[v][0];
     }
     {
         gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
@@ -394,30 +399,28 @@ extern "C" int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
                            cap);
     }
     GS_HIP(hipGetLastError());
-    int kcur = 0;
     {
         gs_prof_scope prof_(ctx, GS_K_SORT);
         for (int p = 0; p < tile_passes; p++) {
             const int shift = p * bits_per_pass;
             const int nbits = (tile_bits - shift < bits_per_pass) ? tile_bits - shift : bits_per_pass;
+            const bool last = p == tile_passes - 1;
             RadixArgs a{};
             a.n = cap;
             for (int v = 0; v < nv; v++) {
-                a.keys_in[v] = tk[v][kcur];
-                a.vals_in[v] = vb[v][cur];
-                a.keys_out[v] = tk[v][kcur ^ 1];
-                a.vals_out[v] = vb[v][cur ^ 1];
+                a.io[v].pairs_in = pp[v][p & 1];
+                a.io[v].pairs_out = pp[v][(p & 1) ^ 1];
+                a.io[v].keys_out = sorted_tiles[v];
+                a.io[v].vals_out = views[v].vals;
                 a.table[v] = (uint32_t *)at(ctx->radix_table, v * tab4);
                 a.n_dev[v] = d_words + v;
             }
-            if ((rc = radix_pass_batch(ctx, nv, a, cap, shift, nbits))) return rc;
-            kcur ^= 1;
-            cur ^= 1;
+            if ((rc = radix_pass_batch(ctx, nv, a, cap, last ? RADIX_PAIRS_TO_SOA : RADIX_PAIRS, shift, nbits))) return rc;
         }
     }
     {
         gs_prof_scope prof_(ctx, GS_K_RANGES);
-        for (int v = 0; v < nv; v++) ra.tile_keys[v] = tk[v][kcur];
+        for (int v = 0; v < nv; v++) ra.tile_keys[v] = sorted_tiles[v];
         hipLaunchKernelGGL(ranges_batch_kernel, dim3(gs_div_up((int)cap, 256), nv), dim3(256), 0, ctx->stream, ra);
     }
     GS_HIP(hipGetLastError());

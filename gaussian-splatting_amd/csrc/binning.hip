@@ -19,12 +19,13 @@
 // A stable sort by tile of a list that is already in (depth, gaussian) order is in
 // (tile, depth, gaussian) order: exactly the reference's per-tile gaus_stack.
 //
-// The radix sort is hand-written for wave64: per pass one histogram kernel (LDS atomics), one scan
-// kernel (one workgroup per digit turns the [digit][block] table into global offsets) and one
-// scatter kernel that ranks 4096 keys per workgroup with ballot matching (stable inside a wave,
-// per-wave counters in LDS across waves), reorders them through LDS and writes each digit run
-// contiguously.
-#include "binning_kernels.h"
+// The radix sort is hand-written for wave64 (radix_sort.h): per pass one histogram kernel (LDS atomics), one scan
+// kernel (one workgroup per digit turns the [digit][block] table into global offsets) and one scatter kernel that
+// ranks 4096 or 8192 elements per workgroup with ballot matching (stable inside a wave, per-wave counters in LDS
+// across waves), reorders them through LDS and writes each digit run contiguously.  The (tile id, gaussian) pairs
+// travel as ONE 8-byte element, so a digit run is one piece of HBM, not two; the last pass splits them into the
+// caller's gaussian ids and the sorted tile ids K5 reads.
+#include "radix_sort.h"
 #include <cstring>
 
 namespace {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
                                                         const int4 *__restrict__ rect,
                                                         const int32_t *__restrict__ depth, Grid grid,
                                                         const uint32_t *__restrict__ offsets,
-                                                        uint32_t *__restrict__ tile_keys, int32_t *__restrict__ vals) {
+                                                        uint2 *__restrict__ pairs) {
     __shared__ uint32_t s_first[4][64];  // exclusive prefix of counts within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
     __shared__ uint32_t s_mark[4][64];
@@ -123,8 +124,7 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
             const uint32_t local = sidx - s_first[wave][lo];
             const int tx = inf.x + (int)(local / (uint32_t)inf.z);
             const int ty = inf.y + (int)(local % (uint32_t)inf.z);
-            tile_keys[out_base + sidx] = (uint32_t)(tx * grid.tiles_y + ty);
-            vals[out_base + sidx] = inf.w;
+            pairs[out_base + sidx] = make_uint2((uint32_t)(tx * grid.tiles_y + ty), (uint32_t)inf.w);
         }
     }
 }
@@ -179,25 +179,24 @@ __global__ __launch_bounds__(256) void culled_pairs_kernel(int N, const int32_t 
                                                            const float4 *__restrict__ rec, CullBox cb,
                                                            uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ offsets, uint32_t D,
-                                                           uint32_t *__restrict__ tile_keys,
-                                                           int32_t *__restrict__ vals) {
-    culled_pairs_body<CULL_EMIT>(blockIdx.x, N, perm, rect, depth, grid, rec, cb, counts, offsets, D, tile_keys, vals);
+                                                           uint2 *__restrict__ pairs) {
+    culled_pairs_body<CULL_EMIT>(blockIdx.x, N, perm, rect, depth, grid, rec, cb, counts, offsets, D, pairs);
 }
-__global__ __launch_bounds__(RADIX_THREADS) void radix_hist_kernel(uint32_t n, const uint32_t *__restrict__ keys,
-                                                                   int shift, uint32_t mask, uint32_t nblocks,
-                                                                   uint32_t *__restrict__ table) {
-    radix_hist_body(blockIdx.x, n, keys, shift, mask, nblocks, table);
+template <int THREADS, bool PAIRS>
+__global__ __launch_bounds__(THREADS) void radix_hist_kernel(uint32_t n, const uint32_t *__restrict__ keys,
+                                                             const uint2 *__restrict__ pairs, int shift, uint32_t mask,
+                                                             uint32_t nblocks, uint32_t *__restrict__ table) {
+    radix2_hist_body<THREADS, RADIX_ITEMS, PAIRS>(blockIdx.x, n, keys, pairs, shift, mask, nblocks, table);
 }
-__global__ __launch_bounds__(RADIX_THREADS) void radix_scan_kernel(uint32_t nblocks, uint32_t *__restrict__ table,
-                                                                   uint32_t *__restrict__ totals) {
+__global__ __launch_bounds__(SCAN_THREADS) void radix_scan_kernel(uint32_t nblocks, uint32_t *__restrict__ table,
+                                                                  uint32_t *__restrict__ totals) {
     radix_scan_body(blockIdx.x, nblocks, table, totals);
 }
-template <int NBITS>
-__global__ __launch_bounds__(RADIX_THREADS) void radix_scatter_kernel(
-    uint32_t n, const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift, uint32_t mask,
-    uint32_t nblocks, const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals) {
-    radix_scatter_body<NBITS>(blockIdx.x, n, keys_in, vals_in, keys_out, vals_out, shift, mask, nblocks, table, totals);
+template <int NBITS, int THREADS, int MODE>
+__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(uint32_t n, RadixIO io, int shift, uint32_t mask,
+                                                                uint32_t nblocks, const uint32_t *__restrict__ table,
+                                                                const uint32_t *__restrict__ totals) {
+    radix2_scatter_body<NBITS, THREADS, RADIX_ITEMS, MODE>(blockIdx.x, n, io, shift, mask, nblocks, table, totals);
 }
 __global__ __launch_bounds__(256) void ranges_kernel(uint32_t D, const uint32_t *__restrict__ tile_keys,
                                                      int32_t *__restrict__ ranges) {
@@ -225,32 +224,51 @@ int check_bin_args(gs_ctx *ctx, int32_t N, const int32_t *rect, const int32_t *d
     return GS_OK;
 }
 
-// one stable LSD pass over n (key, value) pairs on ctx->stream
-int radix_pass(gs_ctx *ctx, uint32_t n, const uint32_t *keys_in, const int32_t *vals_in, uint32_t *keys_out,
-               int32_t *vals_out, int shift, int nbits) {
-    const uint32_t nblocks = (n + RADIX_TILE - 1) / RADIX_TILE;
+// one stable LSD pass over n elements on ctx->stream; `mode` says where they come from and go to (RadixMode)
+template <int THREADS>
+int radix_pass_t(gs_ctx *ctx, uint32_t n, const RadixIO &io, int mode, int shift, int nbits) {
+    constexpr int TILE = THREADS * RADIX_ITEMS;
+    const uint32_t nblocks = (n + TILE - 1) / TILE;
     int rc;
     if ((rc = gs_buf_reserve(ctx, &ctx->radix_table, ((size_t)RADIX_BINS * nblocks + RADIX_BINS) * 4))) return rc;
     uint32_t *totals = (uint32_t *)ctx->radix_table.p;
     uint32_t *table = totals + RADIX_BINS;
     const uint32_t mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RADIX_THREADS), 0, ctx->stream, n, keys_in, shift,
-                       mask, nblocks, table);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, nblocks, table,
-                       totals);
-#define GS_SCATTER(NB)                                                                                          \
-    case NB:                                                                                                    \
-        hipLaunchKernelGGL(radix_scatter_kernel<NB>, dim3(nblocks), dim3(RADIX_THREADS), 0, ctx->stream, n, keys_in, \
-                           vals_in, keys_out, vals_out, shift, mask, nblocks, (const uint32_t *)table,          \
-                           (const uint32_t *)totals);                                                           \
+    if (mode == RADIX_SOA)
+        hipLaunchKernelGGL((radix_hist_kernel<THREADS, false>), dim3(nblocks), dim3(THREADS), 0, ctx->stream, n, io.keys_in,
+                           (const uint2 *)nullptr, shift, mask, nblocks, table);
+    else
+        hipLaunchKernelGGL((radix_hist_kernel<THREADS, true>), dim3(nblocks), dim3(THREADS), 0, ctx->stream, n,
+                           (const uint32_t *)nullptr, io.pairs_in, shift, mask, nblocks, table);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX_BINS), dim3(SCAN_THREADS), 0, ctx->stream, nblocks, table, totals);
+#define GS_SCATTER_M(NB, M)                                                                                         \
+    hipLaunchKernelGGL((radix_scatter_kernel<NB, THREADS, M>), dim3(nblocks), dim3(THREADS), 0, ctx->stream, n, io, \
+                       shift, mask, nblocks, (const uint32_t *)table, (const uint32_t *)totals)
+#define GS_SCATTER(NB)                                                                     \
+    case NB:                                                                               \
+        if (mode == RADIX_SOA) GS_SCATTER_M(NB, RADIX_SOA);                                \
+        else if (mode == RADIX_PAIRS) GS_SCATTER_M(NB, RADIX_PAIRS);                       \
+        else GS_SCATTER_M(NB, RADIX_PAIRS_TO_SOA);                                         \
         break;
     switch (nbits) {
         GS_SCATTER(1) GS_SCATTER(2) GS_SCATTER(3) GS_SCATTER(4) GS_SCATTER(5) GS_SCATTER(6) GS_SCATTER(7) GS_SCATTER(8)
         default: return gs_set_error(GS_ERR_ARG, "radix_pass: %d bits per pass", nbits);
     }
 #undef GS_SCATTER
+#undef GS_SCATTER_M
     GS_HIP(hipGetLastError());
     return GS_OK;
+}
+
+int radix_pass(gs_ctx *ctx, uint32_t n, const RadixIO &io, int mode, int shift, int nbits) {
+    return n >= RADIX_BIG_FROM ? radix_pass_t<RADIX_THREADS_BIG>(ctx, n, io, mode, shift, nbits)
+                               : radix_pass_t<RADIX_THREADS>(ctx, n, io, mode, shift, nbits);
+}
+
+RadixIO soa_io(const uint32_t *keys_in, const int32_t *vals_in, uint32_t *keys_out, int32_t *vals_out) {
+    RadixIO io{};
+    io.keys_in = keys_in; io.vals_in = vals_in; io.keys_out = keys_out; io.vals_out = vals_out;
+    return io;
 }
 
 int bits_of(uint32_t v) {
@@ -271,7 +289,7 @@ int gs_radix_sort_pairs(gs_ctx *ctx, uint32_t n, const uint32_t *keys_in, const 
     for (int p = 0; p < passes; p++) {
         const int shift = p * per_pass;
         const int nbits = bits - shift < per_pass ? bits - shift : per_pass;
-        const int rc = radix_pass(ctx, n, kin, vin, keys[p & 1], vals[p & 1], shift, nbits);
+        const int rc = radix_pass(ctx, n, soa_io(kin, vin, keys[p & 1], vals[p & 1]), RADIX_SOA, shift, nbits);
         if (rc) return rc;
         kin = keys[p & 1];
         vin = vals[p & 1];
@@ -310,8 +328,7 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
             const CullBox cb{(float)tile_size, pixel_offset};
             hipLaunchKernelGGL(culled_pairs_kernel<false>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                                (const int32_t *)nullptr, reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
-                               rec, cb, (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr,
-                               (int32_t *)nullptr);
+                               rec, cb, (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr);
             hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
                                (const uint32_t *)ctx->counts.p, depths, partials);
         } else {
@@ -388,7 +405,8 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
         for (int p = 0; p < depth_passes; p++) {
             const bool last = p == depth_passes - 1;
             const int nbits = last ? (depth_bits - 8 * p > 0 ? depth_bits - 8 * p : 1) : 8;
-            if ((rc = radix_pass(ctx, (uint32_t)N, kin, vin, last ? nullptr : dk[p & 1], dv[p & 1], 8 * p, nbits)))
+            if ((rc = radix_pass(ctx, (uint32_t)N, soa_io(kin, vin, last ? nullptr : dk[p & 1], dv[p & 1]), RADIX_SOA, 8 * p,
+                                 nbits)))
                 return rc;
             kin = dk[p & 1];
             vin = dv[p & 1];
@@ -417,46 +435,47 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     if (tile_bits == 0) tile_bits = 1;
     const int tile_passes = (tile_bits + 7) / 8;
     const int bits_per_pass = (tile_bits + tile_passes - 1) / tile_passes;
-    if ((rc = gs_buf_reserve(ctx, &ctx->keys_tmp, 2 * d4))) return rc;
+    // pairs ping-pong (2 x D x 8 bytes); the last pass writes the caller's vals and the sorted tile ids for K5
+    const size_t d8 = 2 * d4;
+    if ((rc = gs_buf_reserve(ctx, &ctx->keys_tmp, 2 * d8))) return rc;
     if ((rc = gs_buf_reserve(ctx, &ctx->vals_tmp, d4))) return rc;
-    uint32_t *tk[2] = {(uint32_t *)ctx->keys_tmp.p, (uint32_t *)((char *)ctx->keys_tmp.p + d4)};
-    // value buffers alternate so that the last pass writes the caller's array
-    int32_t *vb[2] = {(int32_t *)ctx->vals_tmp.p, vals};
-    int cur = (tile_passes & 1) ? 0 : 1;
+    uint2 *pp[2] = {(uint2 *)ctx->keys_tmp.p, (uint2 *)((char *)ctx->keys_tmp.p + d8)};
+    uint32_t *sorted_tiles = (uint32_t *)ctx->vals_tmp.p;
     {
         gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
         if (rec) {
             const CullBox cb{(float)tile_size, pixel_offset};
             hipLaunchKernelGGL(culled_pairs_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm,
                                rect, depths, grid, rec, cb, (uint32_t *)nullptr, (const uint32_t *)ctx->offsets.p,
-                               (uint32_t)D, tk[0], vb[cur]);
+                               (uint32_t)D, pp[0]);
         } else {
             hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm, rect,
-                               depths, grid, (const uint32_t *)ctx->offsets.p, tk[0], vb[cur]);
+                               depths, grid, (const uint32_t *)ctx->offsets.p, pp[0]);
         }
     }
     GS_HIP(hipGetLastError());
-    int kcur = 0;
     {
         gs_prof_scope prof_(ctx, GS_K_SORT);
         for (int p = 0; p < tile_passes; p++) {
             const int shift = p * bits_per_pass;
             const int nbits = (tile_bits - shift < bits_per_pass) ? tile_bits - shift : bits_per_pass;
-            if ((rc = radix_pass(ctx, (uint32_t)D, tk[kcur], vb[cur], tk[kcur ^ 1], vb[cur ^ 1], shift, nbits)))
-                return rc;
-            kcur ^= 1;
-            cur ^= 1;
+            const bool last = p == tile_passes - 1;
+            RadixIO io{};
+            io.pairs_in = pp[p & 1];
+            io.pairs_out = pp[(p & 1) ^ 1];
+            io.keys_out = sorted_tiles;
+            io.vals_out = vals;
+            if ((rc = radix_pass(ctx, (uint32_t)D, io, last ? RADIX_PAIRS_TO_SOA : RADIX_PAIRS, shift, nbits))) return rc;
         }
     }
-    // here vb[cur] == vals
 
     {
         gs_prof_scope prof_(ctx, GS_K_RANGES);
         hipLaunchKernelGGL(ranges_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream, (uint32_t)D,
-                           (const uint32_t *)tk[kcur], ranges);
+                           (const uint32_t *)sorted_tiles, ranges);
         if (keys)
             hipLaunchKernelGGL(build_keys_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream, (uint32_t)D,
-                               (const uint32_t *)tk[kcur], (const int32_t *)vals, depths, keys);
+                               (const uint32_t *)sorted_tiles, (const int32_t *)vals, depths, keys);
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

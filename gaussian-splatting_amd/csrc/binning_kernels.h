@@ -10,12 +10,11 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;   // elements per block
 
-constexpr int RADIX_THREADS = 256;
-constexpr int RADIX_WAVES = RADIX_THREADS / 64;
-constexpr int RADIX_ITEMS = 16;
-constexpr int RADIX_TILE = RADIX_THREADS * RADIX_ITEMS;      // 4096 keys per workgroup
-constexpr int RADIX_WAVE_TILE = 64 * RADIX_ITEMS;            // 1024 keys per wave
 constexpr int RADIX_BINS = 256;
+constexpr int RADIX_ITEMS = 16;                              // elements per thread of a radix pass
+constexpr int RADIX_THREADS = 256;                           // small sorts: 4096 elements per workgroup
+constexpr int RADIX_THREADS_BIG = 512;                       // large sorts: 8192 (fewer, longer digit runs)
+constexpr uint32_t RADIX_BIG_FROM = 32u << 20;               // elements from which the large tile is used
 
 struct Grid {
     int tiles_x, tiles_y;
@@ -184,8 +183,8 @@ __device__ __forceinline__ bool pair_may_contribute(const float4 geo, const floa
 // One wave per 64 consecutive gaussians; the wave walks the concatenation of their rects 64 pairs at a
 // time (slot_owner finds each pair's gaussian, as in K3), so a gaussian covering thousands of tiles does not
 // serialise its wave.  CULL_EMIT = false: counts[g] <- pairs that pass.  CULL_EMIT = true (gaussians taken
-// in depth order through perm): the passing pairs are written from offsets[first position of the wave]
-// on, compacted with a ballot, i.e. in (depth order, tile order).
+// in depth order through perm): the passing pairs are written as {tile id, gaussian} from offsets[first position
+// of the wave] on, compacted with a ballot, i.e. in (depth order, tile order).
 template <bool CULL_EMIT>
 __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t *__restrict__ perm,
                                                            const int4 *__restrict__ rect,
@@ -193,8 +192,7 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
                                                            const float4 *__restrict__ rec, CullBox cb,
                                                            uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ offsets, uint32_t D,
-                                                           uint32_t *__restrict__ tile_keys,
-                                                           int32_t *__restrict__ vals) {
+                                                           uint2 *__restrict__ pairs) {
     __shared__ uint32_t s_first[4][64];  // exclusive prefix of rect sizes within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
     __shared__ float4 s_geo[4][64], s_con[4][64];
@@ -240,10 +238,8 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
             const unsigned long long m = __ballot(pass);
             if (pass) {
                 const uint32_t pos = out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < D) {     // always true: the count pass ran the same test on the same data
-                    tile_keys[pos] = (uint32_t)(tx * grid.tiles_y + ty);
-                    vals[pos] = s_info[wave][lo].w;
-                }
+                if (pos < D)       // always true: the count pass ran the same test on the same data
+                    pairs[pos] = make_uint2((uint32_t)(tx * grid.tiles_y + ty), (uint32_t)s_info[wave][lo].w);
             }
             out += (uint32_t)__popcll(m);
         } else if (pass) {
@@ -253,159 +249,6 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
     if (!CULL_EMIT) {
         __syncthreads();
         if (i < N) counts[i] = s_pass[wave][lane];
-    }
-}
-
-// ---------------------------------------------------------------------------- radix sort pass
-// digit = (key >> shift) & mask, at most 8 bits.  Block b owns keys [b*4096, (b+1)*4096).
-
-__device__ __forceinline__ void radix_hist_body(int bid, uint32_t n, const uint32_t *__restrict__ keys,
-                                                                   int shift, uint32_t mask, uint32_t nblocks,
-                                                                   uint32_t *__restrict__ table) {
-    __shared__ uint32_t h[RADIX_BINS];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = bid * (uint32_t)RADIX_TILE;
-    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);   // base is a multiple of 4096
-#pragma unroll
-    for (int k = 0; k < RADIX_ITEMS / 4; k++) {
-        const uint32_t e = (k * RADIX_THREADS + threadIdx.x) * 4u;
-        const uint32_t i = base + e;
-        if (i + 3 < n) {
-            const uint4 v = k4[k * RADIX_THREADS + threadIdx.x];
-            atomicAdd(&h[(v.x >> shift) & mask], 1u);
-            atomicAdd(&h[(v.y >> shift) & mask], 1u);
-            atomicAdd(&h[(v.z >> shift) & mask], 1u);
-            atomicAdd(&h[(v.w >> shift) & mask], 1u);
-        } else {
-            for (uint32_t j = i; j < n && j < i + 4; j++) atomicAdd(&h[(keys[j] >> shift) & mask], 1u);
-        }
-    }
-    __syncthreads();
-    table[threadIdx.x * nblocks + bid] = h[threadIdx.x];
-}
-
-// one workgroup per digit: table[d][b] <- keys with digit d in blocks before b; totals[d] <- keys
-// with digit d.  (No atomics: thousands of same-address atomics serialise at ~12 ns each.)
-__device__ __forceinline__ void radix_scan_body(int bid, uint32_t nblocks, uint32_t *__restrict__ table,
-                                                                   uint32_t *__restrict__ totals) {
-    const uint32_t d = bid;
-    uint32_t *row = table + (size_t)d * nblocks;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nblocks; base += RADIX_THREADS) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? row[i] : 0u;
-        uint32_t total;
-        const uint32_t excl = block_exclusive_scan(v, &total);
-        if (i < nblocks) row[i] = carry + excl;
-        carry += total;
-    }
-    if (threadIdx.x == 0) totals[d] = carry;
-}
-
-// vals_in == nullptr: the value of key i is i (first pass of the depth sort).
-// keys_out == nullptr: only the values are wanted (last pass of the depth sort).
-// NBITS (digit width) is a template parameter: the ballot matching below is the kernel's cost (it is bound
-// by instruction issue, not by HBM), and a runtime width puts a branch around every one of its steps.
-template <int NBITS>
-__device__ __forceinline__ void radix_scatter_body(int bid,
-    uint32_t n, const uint32_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift, uint32_t mask,
-    uint32_t nblocks, const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals) {
-    __shared__ uint32_t s_cnt[RADIX_WAVES][RADIX_BINS];   // per-wave digit counts -> exclusive wave bases
-    __shared__ uint32_t s_lbase[RADIX_BINS];              // where digit d starts inside this block
-    __shared__ uint32_t s_gbase[RADIX_BINS];              // global start of (d, block) minus s_lbase[d]
-    __shared__ uint32_t s_keys[RADIX_TILE];
-    __shared__ int32_t s_vals[RADIX_TILE];
-
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t base = bid * (uint32_t)RADIX_TILE;
-    if (base >= n) return;     // whole workgroup (a grid sized by an upper bound of n); before any barrier
-    const uint32_t wbase = base + (uint32_t)w * RADIX_WAVE_TILE;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-
-    for (int c = t; c < RADIX_WAVES * RADIX_BINS; c += RADIX_THREADS) (&s_cnt[0][0])[c] = 0u;
-
-    // wave-striped arrangement: the block's key order is (wave, item, lane)
-    uint32_t key[RADIX_ITEMS], rank[RADIX_ITEMS];
-    int32_t val[RADIX_ITEMS];
-#pragma unroll
-    for (int k = 0; k < RADIX_ITEMS; k++) {
-        const uint32_t i = wbase + k * 64 + lane;
-        key[k] = 0xFFFFFFFFu;
-        val[k] = 0;
-        if (i < n) {
-            key[k] = keys_in[i];
-            val[k] = vals_in ? vals_in[i] : (int32_t)i;
-        }
-    }
-    __syncthreads();
-
-    // plain LDS accesses: a volatile pointer here decays to a generic one and every counter access becomes a
-    // flat load / store with a full wait.  LDS operations of one wave execute in order; the fences keep the
-    // compiler from moving them across each other.
-    uint32_t *cnt = &s_cnt[w][0];
-#pragma unroll
-    for (int k = 0; k < RADIX_ITEMS; k++) {
-        const bool valid = wbase + k * 64 + lane < n;
-        const uint32_t d = (key[k] >> shift) & mask;
-        // lanes of this wave holding the same digit: per bit, keep the lanes whose bit equals mine.
-        // ~(ballot ^ m) with m = all ones where my bit is set: one xnor + one and per half and bit.
-        const unsigned long long vb = __ballot(valid);
-        uint32_t peers_lo = (uint32_t)vb, peers_hi = (uint32_t)(vb >> 32);
-#pragma unroll
-        for (int b = 0; b < NBITS; b++) {
-            const uint32_t bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit != 0u);
-            const uint32_t m = 0u - bit;
-            peers_lo &= ~((uint32_t)bal ^ m);
-            peers_hi &= ~((uint32_t)(bal >> 32) ^ m);
-        }
-        const unsigned long long peers = ((unsigned long long)peers_hi << 32) | peers_lo;
-        const uint32_t r = __popc(peers_lo & (uint32_t)lt) + __popc(peers_hi & (uint32_t)(lt >> 32));
-        const uint32_t prev = cnt[d];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (valid && r == 0) cnt[d] = prev + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        rank[k] = prev + r;     // position among this wave's keys of digit d
-    }
-    __syncthreads();
-
-    {   // thread t = digit t
-        uint32_t run = 0;
-#pragma unroll
-        for (int ww = 0; ww < RADIX_WAVES; ww++) {
-            const uint32_t c = s_cnt[ww][t];
-            s_cnt[ww][t] = run;
-            run += c;
-        }
-        uint32_t block_total, all;
-        const uint32_t excl = block_exclusive_scan(run, &block_total);
-        const uint32_t dbase = block_exclusive_scan(totals[t], &all);   // keys with a smaller digit
-        s_lbase[t] = excl;
-        s_gbase[t] = dbase + table[(size_t)t * nblocks + bid] - excl;
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int k = 0; k < RADIX_ITEMS; k++) {
-        if (wbase + k * 64 + lane < n) {
-            const uint32_t d = (key[k] >> shift) & mask;
-            const uint32_t pos = s_lbase[d] + s_cnt[w][d] + rank[k];
-            s_keys[pos] = key[k];
-            s_vals[pos] = val[k];
-        }
-    }
-    __syncthreads();
-
-    const uint32_t count = min((uint32_t)RADIX_TILE, n - base);
-    for (uint32_t i = t; i < count; i += RADIX_THREADS) {
-        const uint32_t kk = s_keys[i];
-        const uint32_t pos = s_gbase[(kk >> shift) & mask] + i;
-        if (keys_out) keys_out[pos] = kk;
-        vals_out[pos] = s_vals[i];
     }
 }
 
