@@ -68,7 +68,9 @@ def parse():
                     help="which kernels get HIP events inside the timed region")
     ap.add_argument("--k8-early-lanes", type=int, default=None,
                     help="lanes whose views get an early parameter-backward launch (default: half of them)")
-    ap.add_argument("--concurrent-views", type=int, default=4, help="local views in flight on separate streams")
+    ap.add_argument("--concurrent-views", type=int, default=None,
+                    help="local views in flight on separate streams (default: train_step's own rule, 4 lanes, or 2 "
+                         "when a view carries >= 32 M (gaussian, tile) pairs)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: single-view forward render")
     return ap.parse_args()
 
@@ -429,7 +431,7 @@ def main():
                                    "stays visible in every view",
                        "n_visible": n_visible, "duplicates_D": int(D), "visited_D_star": d_star,
                        "max_tile_list": max_len, "pixels_per_thread": 4,
-                       "concurrent_views_per_rank": args.concurrent_views,
+                       "concurrent_views_per_rank": args.concurrent_views or gs.auto_lanes(pipe),
                        "lists": args.lists, "lists_note": LISTS_NOTE[args.lists], "ranks_seen": ranks_seen},
             "ranks_seen": ranks_seen,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "other_lists": other_lists, "kernels": kernels,

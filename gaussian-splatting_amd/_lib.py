@@ -59,6 +59,7 @@ SIGNATURES = {
     "gs_ctx_set_stream": (ctypes.c_int, [_P, _P]),
     "gs_ctx_destroy": (ctypes.c_int, [_P]),
     "gs_ctx_info": (_I64, [_P, ctypes.c_char_p]),
+    "gs_ctx_reserve": (ctypes.c_int, [_P, _I32, _I64, _I32, _I32, _I32, _I32]),
     "gs_ctx_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, _I32]),
     "gs_profile_kernel_count": (ctypes.c_int, []),
     "gs_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),

@@ -108,6 +108,12 @@ class DeviceContext:
             raise GsError(f"gs_ctx_info: unknown name '{name}'")
         return v
 
+    def reserve(self, n_max, d_max, result_size, tile_size=16, arrays=False):
+        """gs_ctx_reserve: size this context's workspace once for up to n_max gaussians and d_max list entries per
+        view, so that no later call regrows it in the middle of a step."""
+        check(self.lib.gs_ctx_reserve(self.handle, int(n_max), int(d_max), int(result_size[0]), int(result_size[1]),
+                                      int(tile_size), int(bool(arrays))), "gs_ctx_reserve")
+
     def profile(self, enable=True):
         """Bracket every kernel launch with HIP events (see read_profile)."""
         check(self.lib.gs_ctx_profile(self.handle, int(bool(enable))), "gs_ctx_profile")

@@ -489,6 +489,33 @@ int cull_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colo
 
 }  // namespace
 
+// Workspace of the per-view entry points for up to N_max gaussians and D_max list entries, allocated once.
+extern "C" int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t res_w, int32_t res_h,
+                              int32_t tile_size, int32_t array_api) {
+    GS_REQUIRE(ctx, "gs_ctx_reserve: ctx is NULL");
+    GS_REQUIRE(N_max >= 0 && D_max >= 0 && D_max < (1ll << 31), "gs_ctx_reserve: N_max=%d D_max=%lld out of range", N_max,
+               (long long)D_max);
+    GS_REQUIRE(res_w > 0 && res_h > 0 && tile_size > 0, "gs_ctx_reserve: invalid frame %dx%d tile %d", res_w, res_h,
+               tile_size);
+    GS_HIP(hipSetDevice(ctx->device));
+    const size_t N = (size_t)(N_max > 0 ? N_max : 1), D = (size_t)(D_max > 0 ? D_max : 1);
+    const size_t n4 = (N * 4 + 255) & ~(size_t)255, d4 = (D * 4 + 255) & ~(size_t)255;
+    const size_t small_tile = (size_t)RADIX_THREADS * RADIX_ITEMS;
+    const size_t radix_blocks = ((N > D ? N : D) + small_tile - 1) / small_tile;       // the small tile bounds both
+    const size_t blocks16 = (size_t)gs_div_up(res_w, 16) * gs_div_up(res_h, 16);
+    struct { gs_buf *b; size_t bytes; } want[] = {
+        {&ctx->counts, N * 4}, {&ctx->total, 16 + COUNT_BLOCKS * sizeof(ulonglong2)}, {&ctx->depth_sort, 4 * n4},
+        {&ctx->offsets, N * 4}, {&ctx->block_sums, (size_t)gs_div_up((int)N, SCAN_TILE) * 4}, {&ctx->keys_tmp, 4 * d4},
+        {&ctx->vals_tmp, d4}, {&ctx->radix_table, ((size_t)RADIX_BINS * radix_blocks + RADIX_BINS) * 4},
+        {&ctx->tile_order_buf, blocks16 * 2 * sizeof(int32_t)}, {&ctx->loss_partials, 1024 * sizeof(double)},
+        {&ctx->packed, array_api ? N * 64 : 0}, {&ctx->grad_rows, array_api ? N * 64 : 0}};
+    for (auto &w : want)
+        if (w.bytes)
+            if (const int rc = gs_buf_reserve(ctx, w.b, w.bytes, true)) return rc;
+    if (!ctx->count_event) GS_HIP(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
+    return GS_OK;
+}
+
 extern "C" int gs_bin_count(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
                             int32_t res_w, int32_t res_h, int32_t tile_size, int64_t *D_host) {
     int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);

@@ -94,7 +94,7 @@ struct gs_ctx {
     int64_t allocations = 0;          // hipMallocs made by gs_buf_reserve since the ctx was created
 };
 
-int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes);
+int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes, bool exact = false);
 // ctx.hip: bounded host wait for an event (error instead of a hang when the stream never gets there)
 int gs_wait_event(gs_ctx *ctx, hipEvent_t ev, const char *what);
 // blend.hip: looks up this device's copy of the static scratch array (gs_blend_backward_noalloc); device must be current

@@ -22,7 +22,7 @@ int gs_set_error(int code, const char *fmt, ...) {
 extern "C" const char *gs_last_error(void) { return g_err; }
 extern "C" int gs_version(void) { return 1; }
 
-int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes) {
+int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes, bool exact) {
     if (bytes <= b->cap) return GS_OK;
     // the old block may still be in use by work queued on the stream
     GS_HIP(hipStreamSynchronize(ctx->stream));
@@ -30,7 +30,7 @@ int gs_buf_reserve(gs_ctx *ctx, gs_buf *b, size_t bytes) {
     ctx->workspace_bytes -= b->cap;
     b->p = nullptr;
     b->cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = exact ? bytes + 256 : bytes + bytes / 4 + 256;   // reserve-ahead calls name the final size
     GS_HIP(hipMalloc(&b->p, want));
     b->cap = want;
     ctx->workspace_bytes += want;

@@ -21,12 +21,18 @@ class Densifier:
         self.grad_threshold, self.percent_dense = float(grad_threshold), float(percent_dense)
         self.min_opacity, self.split_factor = float(min_opacity), float(split_factor)
         self.max_gaussians = max_gaussians
-        self.gen = torch.Generator(device=pipe.ctx.device).manual_seed(int(seed))
+        # host generator: the draws depend on the seed alone (not on the device or its RNG implementation), so every
+        # rank applies identical changes and a CPU restatement can be given the very same samples
+        self.gen = torch.Generator(device="cpu").manual_seed(int(seed))
         if scene_extent is None:
             c = pipe.means
             scene_extent = float((c - c.mean(dim=0)).norm(dim=1).max().item()) * 1.1
         self.scene_extent = scene_extent
         self.reset()
+
+    def sample(self, n):
+        """[n,3] standard-normal draws for the split children (one call per child generation)."""
+        return torch.randn(n, 3, generator=self.gen, dtype=torch.float32)
 
     def reset(self):
         dev = self.pipe.ctx.device
@@ -92,7 +98,7 @@ class Densifier:
                              2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
             std = self._activated_scales()[split_mask]
             for _ in range(2):
-                eps = torch.randn(n_split, 3, generator=self.gen, device=sm.device, dtype=torch.float32)
+                eps = self.sample(n_split).to(sm.device)
                 offs = torch.bmm(R, (eps * std).unsqueeze(-1)).squeeze(-1)
                 children.append([sm + offs, ss - torch.log(torch.tensor(self.split_factor, device=sm.device)), sq, so, ssh])
         keep = ~split_mask & ~prunable

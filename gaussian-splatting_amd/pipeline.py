@@ -113,6 +113,23 @@ class SplatPipeline:
         """Every DeviceContext this pipeline launches on (for profiling)."""
         return [self.ctx] + [c for c, _ in self._lanes] + list(self._alts)
 
+    def reserve(self, n_max, d_max, concurrent_views=4):
+        """Reserve ahead on every context a step with `concurrent_views` lanes launches on (main, lanes, their
+        alternates): workspace for views of up to n_max gaussians and d_max (gaussian, tile) pairs.  A training loop
+        whose gaussian count grows (densification) calls this once with its budget; afterwards
+        sum(c.info("allocations") for c in contexts()) stays constant."""
+        n = max(1, int(concurrent_views))
+        self.lanes(n - 1 if n > 3 else n)
+        self.alt_contexts(n)
+        for c in self.contexts():
+            c.reserve(n_max, d_max, self.result_size, self.tile_size)
+
+    def workspace_bytes(self):
+        return sum(c.info("workspace_bytes") for c in self.contexts())
+
+    def allocations(self):
+        return sum(c.info("allocations") for c in self.contexts())
+
     def export(self):
         """The current parameters as a host GaussianSet (float64 NumPy, the reference's dtypes)."""
         f = lambda t: t.detach().cpu().numpy().astype(np.float64)
@@ -462,13 +479,25 @@ def _all_reduce(pipe, tensors, works):
     all_reduce_sum(pipe.ctx, tensors, works)
 
 
+BIG_VIEW_PAIRS = 32 << 20      # (gaussian, tile) pairs per view from which two lanes beat four (measured, 10 M / 4K)
+
+
+def auto_lanes(pipe):
+    """Views in flight for train_step(concurrent_views=None): four lanes while a view's lists are small (the blend
+    kernels' tails overlap), two once a view carries tens of millions of pairs -- its sorts are then HBM-bound for
+    milliseconds and four of them at once only stretch each other (10 M gaussians at 3840x2160, 122 M pairs per
+    view, 4 views per step: 22.99 / 21.77 / 22.16 / 22.90 ms with 1 / 2 / 3 / 4 lanes)."""
+    return 2 if int(pipe.stats.get("D", 0)) >= BIG_VIEW_PAIRS else 4
+
+
 def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,
                k8_early_lanes=None, allreduce_chunks=4, batch_binning=False, bin_group=4):
     """Forward+backward over this rank's shard of `views`, then the all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
     formed together with dL/dimage by the fused native kernel.  concurrent_views > 1 renders that
-    many local views at a time on separate streams (the 4th is the main stream).  The views of the
+    many local views at a time on separate streams (the 4th is the main stream; None: auto_lanes, by the size of
+    the last view's lists).  The views of the
     first k8_early_lanes lanes (default: half of them) get their parameter backward as soon as they are
     complete, under the blend kernels of the lanes still running.  With more than one rank the last
     parameter-backward launch runs over `allreduce_chunks` ranges of gaussians, and the SH gradients of a
@@ -485,6 +514,8 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     mine = shard_views(len(views), rank, world)
     scale = 1.0 if loss_scale is None else loss_scale
     states = []
+    if concurrent_views is None:
+        concurrent_views = auto_lanes(pipe)
     n_lanes = min(int(concurrent_views), len(mine))
     losses = torch.zeros(max(len(mine), 1), dtype=torch.float32, device=pipe.ctx.device)
     late = None

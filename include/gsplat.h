@@ -58,6 +58,16 @@ int gs_ctx_destroy(gs_ctx *ctx);
  * "allocations" = hipMallocs it has made since it was created (a grow-only arena: a training loop that
  * reserved ahead checks that a step adds none).  Returns -1 for an unknown name. */
 int64_t gs_ctx_info(gs_ctx *ctx, const char *name);
+/* Reserve ahead (no reference counterpart): sizes the ctx's workspace once for views of up to N_max gaussians and
+ * D_max list entries at this frame, so that no later call on the ctx allocates -- without it a buffer that has
+ * become too small is regrown in the middle of a step (stream synchronisation + hipFree + hipMalloc), which is
+ * what a training loop with a growing gaussian count (BASELINE configs[3]) would otherwise pay after every
+ * densification.  array_api != 0 also reserves the packed records and gradient rows that the array-based entry
+ * points keep (64 bytes per gaussian each); callers that hand over records and rows (gs_ctx_use_records,
+ * gs_blend_backward_rows) pass 0.  The ordered K7 reduction's buffers (option deterministic_backward) are not
+ * covered.  About 20 bytes per gaussian + 20 bytes per list entry. */
+int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t res_w, int32_t res_h, int32_t tile_size,
+                   int32_t array_api);
 /* Tuning knobs (no reference counterpart).  "pixels_per_thread": 1, 2 or 4 pixels of a tile
  * column per thread in the blend kernels (default 4 = one wavefront per 16x16 tile; also read
  * from the environment variable GSPLAT_PPT at ctx creation).

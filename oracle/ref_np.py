@@ -383,3 +383,70 @@ def blend_forward_py(centers, colors, opacities, conics, vals, ranges, result_si
                     contrib[x, y] = n
                     Tf[x, y] = T
     return image, contrib, Tf
+
+
+# ---------------------------------------------------------------- the device's own branch decisions, for gradient tests
+def _fma32(a, b, c):
+    """float32 fused multiply-add: the product of two float32 is exact in float64, one rounding at the end."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def device_decisions(centers, conics, opacities, vals, ranges, result_size, tile_size, pixel_offset, n_contrib):
+    """The branches K6 / K7 took, for ref_torch.blend(forced=...): a gradient oracle that follows them can be
+    compared on EVERY pixel, the ones included where fp32 lands on the other side of one of the reference's
+    discontinuities (rasterize.c:109-119: power > 0, alpha < 1/255, T < 1e-4).
+
+    From the device's output n_contrib[W,H] (bits 0..30 = list entries visited, the breaking one included =
+    rasterize.c's last_contributors; bit 31 = left through the transmittance break) and from the validity of
+    every (pixel, list entry) pair recomputed here in float32 with the arithmetic of the kernels (csrc/blend.hip,
+    blend_fwd_quad_kernel: log2-scaled conic, the far pixels of a 16x16 block 8 px on by one subtraction,
+    p = fma(dx, fma(b', dy, a' dx), (c' dy) dy), valid = p <= 0 and not(min(.99, o * 2^p) < 1/255)).
+    Returns dict(visited[tiles,P], broke[tiles,P], valid[tiles,L,P]) in ref_torch.blend's layout (P = tile_size^2,
+    pixel lx * tile_size + ly)."""
+    W, H = int(result_size[0]), int(result_size[1])
+    ts = int(tile_size)
+    tx_n, ty_n = tile_grid(result_size, ts)
+    tiles, P = tx_n * ty_n, ts * ts
+    f32 = np.float32
+    cen, con, opa = np.asarray(centers, f32), np.asarray(conics, f32), np.asarray(opacities, f32).reshape(-1)
+    LOG2E = f32(1.4426950408889634)
+    a2 = (f32(-0.5) * LOG2E) * con[:, 0]
+    b2 = (-LOG2E) * con[:, 1]
+    c2 = (f32(-0.5) * LOG2E) * con[:, 2]
+    off = f32(pixel_offset)
+    ranges = np.asarray(ranges).reshape(tiles, 2)
+    lens = ranges[:, 1] - ranges[:, 0]
+    L = int(lens.max()) if tiles else 0
+    lx = np.repeat(np.arange(ts), ts)
+    ly = np.tile(np.arange(ts), ts)
+    nc = np.asarray(n_contrib).astype(np.int64)
+    visited = np.zeros((tiles, P), dtype=np.int64)
+    broke = np.zeros((tiles, P), dtype=bool)
+    valid = np.zeros((tiles, L, P), dtype=bool)
+    for t in range(tiles):
+        tx, ty = t // ty_n, t % ty_n
+        px, py = tx * ts + lx, ty * ts + ly
+        inside = (px < W) & (py < H)
+        v = nc[np.minimum(px, W - 1), np.minimum(py, H - 1)]
+        visited[t] = np.where(inside, v & 0x7FFFFFFF, 0)
+        broke[t] = inside & ((v >> 31) & 1).astype(bool)
+        n = int(lens[t])
+        if n == 0:
+            continue
+        g = np.asarray(vals[ranges[t, 0]:ranges[t, 1]]).astype(np.int64)
+        # near pixel of the lane's quadrant, then one subtraction of 8 for the far ones
+        bx, by = (px // 16) * 16, (py // 16) * 16
+        fx0 = (bx + px % 8).astype(f32) - off
+        fy0 = (by + py % 8).astype(f32) - off
+        dx = cen[g, 0][:, None] - fx0[None, :]
+        dy = cen[g, 1][:, None] - fy0[None, :]
+        dx = np.where((px % 16 >= 8)[None, :], dx - f32(8.0), dx).astype(f32)
+        dy = np.where((py % 16 >= 8)[None, :], dy - f32(8.0), dy).astype(f32)
+        adx = (a2[g][:, None] * dx).astype(f32)
+        cdy = (c2[g][:, None] * dy).astype(f32)
+        p = _fma32(dx, _fma32(np.broadcast_to(b2[g][:, None], dx.shape), dy, adx), (cdy * dy).astype(f32))
+        with np.errstate(over="ignore", invalid="ignore"):
+            G = np.exp2(p.astype(np.float64)).astype(f32)
+            alpha = np.minimum(f32(0.99), (opa[g][:, None] * G).astype(f32))
+            valid[t, :n] = (p <= 0) & ~(alpha < f32(1.0 / 255.0))
+    return dict(visited=visited, broke=broke, valid=valid)

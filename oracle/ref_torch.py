@@ -104,9 +104,12 @@ def preprocess(means, log_scales, quats, sh, degree, fx, fy, cam_width, cam_heig
 
 
 def blend(centers, colors, opacities, conics, vals, ranges, result_size, tile_size=16,
-          background=(0, 0, 0), pixel_offset=0.5):
+          background=(0, 0, 0), pixel_offset=0.5, forced=None):
     """Differentiable rasterize.c:82-131 over the whole frame, vectorised across tiles and the
-    256 pixels of a tile; sequential over list position.  Returns image[W,H,3]."""
+    256 pixels of a tile; sequential over list position.  Returns image[W,H,3].
+    forced = ref_np.device_decisions(...): the skip / break branches are not decided here but taken as the
+    device took them (which entries a pixel visited, whether it left through the break, which visited pairs were
+    valid), so the derivative is that of the very function the kernels evaluated -- on every pixel."""
     W, H = int(result_size[0]), int(result_size[1])
     tx_n, ty_n = ref_np.tile_grid(result_size, tile_size)
     tiles = tx_n * ty_n
@@ -137,9 +140,14 @@ def blend(centers, colors, opacities, conics, vals, ranges, result_size, tile_si
         # pairs with power > 0 are skipped below; clamping keeps exp() finite there so that autograd does not
         # turn their masked-out branch into 0 * inf = NaN (indefinite conics)
         alpha = torch.clamp(opacities[g][:, None] * torch.exp(torch.clamp(power, max=0.0)), max=.99)
-        active = has[:, None] & ~done & ~(power > 0) & ~(alpha < (1.0 / 255))
         test_T = T * (1.0 - alpha)
-        brk = active & (test_T < .0001)
+        if forced is None:
+            active = has[:, None] & ~done & ~(power > 0) & ~(alpha < (1.0 / 255))
+            brk = active & (test_T < .0001)
+        else:
+            seen = torch.as_tensor(forced["visited"] > j)
+            active = has[:, None] & seen & torch.as_tensor(forced["valid"][:, j, :])
+            brk = active & torch.as_tensor(forced["broke"] & (forced["visited"] == j + 1))
         done = done | brk
         take = active & ~brk
         w = torch.where(take, alpha * T, torch.zeros_like(T))

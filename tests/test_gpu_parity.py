@@ -1168,3 +1168,62 @@ def test_batched_binning_edge_cases(gpu_ctx):
     assert out[0].true_D() > 0
     with pytest.raises(gs.GsError):
         gs.api.bin_culled_batch(gpu_ctx, pres * 5, rs, 16, pipe.pixel_offset, capacity=10)
+
+
+# ------------------------------------------------------------------ K7 on 100 % of the pixels
+def _blend_case(name):
+    """(centers, colors, opacities, conics) float32 + lists builder for the all-pixel gradient test."""
+    if name.startswith("adv"):
+        W, H = 96, 80
+        cen, col, opa, con = _adversarial_2d(int(name[3:]), W, H)
+        return cen, col, opa, con, [W, H], None
+    d = as_record(*dense_scene(), bg=(.2, .1, .3)) if name == "dense" else load_scene(name)
+    return None, None, None, None, None, d
+
+
+@pytest.mark.parametrize("name", ["dense", "s1", "s3", "adv1", "adv2"])
+@pytest.mark.parametrize("lists", ["exact", "culled"])
+def test_blend_backward_on_every_pixel_with_the_device_decisions(gpu_ctx, name, lists):
+    """K7 compared on 100 % of the pixels, fragile ones included, with a dense random dL/dimage that is NOT zeroed
+    anywhere: the fp64 autograd oracle is told the branches the device took (entries visited per pixel and the break
+    bit from n_contrib; validity of every visited pair recomputed in float32 with the kernels' arithmetic,
+    ref_np.device_decisions), so both sides differentiate the same function (rasterize.c:109-119 decides, the
+    branches carry no gradient).  All nine outputs (d centre 2, d conic 3, d opacity, d colour 3) within 1e-4 of
+    the largest reference entry, and the forward image of the forced oracle equals the device's on every pixel."""
+    import torch
+    import gsplat_amd as gs
+    cen, col, opa, con, rs, d = _blend_case(name)
+    dev = gpu_ctx.device
+    bg = np.array([0.2, 0.4, 0.1])
+    if d is None:
+        n = len(cen)
+        W, H = rs
+        tt = np.tile(np.array([[[0, 0], [W // 16, H // 16]]], dtype=np.int32), (n, 1, 1))
+        dep = np.random.default_rng(5).permutation(n).astype(np.int32) + 1
+        rad = np.ones(n)
+    else:
+        cam, R, t, g, rs, bg = scene_inputs(d)
+        cen, dep, col, con, tt, rad = (np.asarray(a) for a in _fwd(gpu_ctx, d, training=False))
+        cen, col, con = cen.astype(np.float32), col.astype(np.float32), con.astype(np.float32)
+        opa = np.asarray(g.opacity, dtype=np.float32)
+    t_ = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    cull = (t_(cen), t_(col), t_(opa), t_(con), 0.5) if lists == "culled" else None
+    b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, rad, dep, result_size=rs, tile_size=16, cull=cull)
+    bg3 = gs.api._bg3(np.asarray(bg))
+    img, nc, tf = gs.api.blend_forward(gpu_ctx, t_(cen), t_(col), t_(opa), t_(con), b, bg3, 0.5)
+    vals, ranges = b.vals.cpu().numpy(), b.ranges.cpu().numpy()
+    forced = ref_np.device_decisions(cen, con, opa, vals, ranges, rs, 16, 0.5, nc.cpu().numpy())
+    p = [torch.tensor(a.astype(np.float64), requires_grad=True) for a in (cen, col, opa, con)]
+    ref_img = ref_torch.blend(p[0], p[1], p[2], p[3], vals, ranges, rs, 16, bg, 0.5, forced=forced)
+    got_img = img.cpu().numpy().astype(np.float64)
+    err = np.abs(got_img - ref_img.detach().numpy())
+    assert err.max() <= 3e-5 + 1e-4 * np.abs(got_img).max(), f"forced forward differs: {err.max():.3e}"   # EVERY pixel
+    wimg = np.random.default_rng(21).normal(size=(rs[0], rs[1], 3)).astype(np.float32)     # dense, nothing masked
+    (ref_img * torch.tensor(wimg, dtype=torch.float64)).sum().backward()
+    d_cen, d_con, d_opa, d_col = gs.api.blend_backward(gpu_ctx, t_(cen), t_(col), t_(opa), t_(con), b, bg3, 0.5, nc, tf,
+                                                       t_(wimg))
+    for got, want, what in ((d_cen, p[0].grad, "centers"), (d_col, p[1].grad, "colors"), (d_opa, p[2].grad, "opacity"),
+                            (d_con, p[3].grad, "conics")):
+        gnp = got.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(gnp)), what
+        _assert_grad(gnp, want.numpy(), f"{name}/{lists} all-pixel {what}", tol=1e-4)
