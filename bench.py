@@ -72,6 +72,8 @@ def parse():
                     help="local views in flight on separate streams (default: train_step's own rule, 4 lanes, or 2 "
                          "when a view carries >= 32 M (gaussian, tile) pairs)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: single-view forward render")
+    ap.add_argument("--prepared-lists", action="store_true",
+                    help="train_step(prepared=True): count / depth order / offsets per batch of views on the main stream")
     return ap.parse_args()
 
 
@@ -193,7 +195,7 @@ def main():
             image, _ = pipe.forward(views[0])
             return image
         return gs.train_step(pipe, views, targets, grads, concurrent_views=args.concurrent_views,
-                             k8_early_lanes=args.k8_early_lanes)
+                             k8_early_lanes=args.k8_early_lanes, prepared=args.prepared_lists)
 
     trace = os.environ.get("GS_BENCH_TRACE") == "1"
 
@@ -367,7 +369,7 @@ def main():
         other_kind = "culled" if args.lists == "exact" else "exact"
         other_pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx, cull_tiles=other_kind == "culled")
         run = lambda: gs.train_step(other_pipe, views, targets, grads, concurrent_views=args.concurrent_views,
-                                    k8_early_lanes=args.k8_early_lanes)
+                                    k8_early_lanes=args.k8_early_lanes, prepared=args.prepared_lists)
         for _ in range(3):
             run()
         torch.cuda.synchronize()

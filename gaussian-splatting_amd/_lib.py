@@ -21,6 +21,11 @@ class GsViewBin(ctypes.Structure):
                 ("vals", ctypes.c_void_p), ("ranges", ctypes.c_void_p), ("D_dev", ctypes.c_void_p)]
 
 
+class GsViewPrepare(ctypes.Structure):
+    _fields_ = [("tiles_touched", ctypes.c_void_p), ("depths", ctypes.c_void_p), ("records", ctypes.c_void_p),
+                ("perm", ctypes.c_void_p), ("offsets", ctypes.c_void_p)]
+
+
 class GsViewBackward(ctypes.Structure):
     _fields_ = [("cam", ctypes.POINTER(GsCamera)), ("radii", ctypes.c_void_p), ("clamped", ctypes.c_void_p),
                 ("grad_rows", ctypes.c_void_p)]
@@ -59,7 +64,7 @@ SIGNATURES = {
     "gs_ctx_set_stream": (ctypes.c_int, [_P, _P]),
     "gs_ctx_destroy": (ctypes.c_int, [_P]),
     "gs_ctx_info": (_I64, [_P, ctypes.c_char_p]),
-    "gs_ctx_reserve": (ctypes.c_int, [_P, _I32, _I64, _I32, _I32, _I32, _I32]),
+    "gs_ctx_reserve": (ctypes.c_int, [_P, _I32, _I64, _I32, _I32, _I32, _I32, _I32]),
     "gs_ctx_set_option": (ctypes.c_int, [_P, ctypes.c_char_p, _I32]),
     "gs_profile_kernel_count": (ctypes.c_int, []),
     "gs_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -81,6 +86,11 @@ SIGNATURES = {
     "gs_bin_bounds_batch": (ctypes.c_int, [_P, _I32, _I32, ctypes.POINTER(GsViewBin), _I32, _I32, _I32, ctypes.POINTER(_I64)]),
     "gs_bin_culled_batch": (ctypes.c_int, [_P, _I32, _I32, ctypes.POINTER(GsViewBin), _I32, _I32, _I32, ctypes.c_float, _I32,
                                            _I64]),
+    "gs_bin_prepare_begin": (ctypes.c_int, [_P, _I32, _I32, ctypes.POINTER(GsViewPrepare), _I32, _I32, _I32, ctypes.c_float]),
+    "gs_bin_prepare_end": (ctypes.c_int, [_P, _I32, _I32, ctypes.POINTER(GsViewPrepare), _I32, _I32, _I32,
+                                          ctypes.POINTER(_I64)]),
+    "gs_bin_fill_prepared": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, ctypes.c_float, _P, _P,
+                                            _P]),
     "gs_bin_fill_culled": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, ctypes.c_float, _I64,
                                           _P, _P, _P]),
     "gs_blend_forward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),

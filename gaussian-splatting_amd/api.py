@@ -108,11 +108,12 @@ class DeviceContext:
             raise GsError(f"gs_ctx_info: unknown name '{name}'")
         return v
 
-    def reserve(self, n_max, d_max, result_size, tile_size=16, arrays=False):
+    def reserve(self, n_max, d_max, result_size, tile_size=16, arrays=False, batch_views=0):
         """gs_ctx_reserve: size this context's workspace once for up to n_max gaussians and d_max list entries per
-        view, so that no later call regrows it in the middle of a step."""
+        view (batch_views > 0: also for gs_bin_prepare_* batches of that many views), so that no later call regrows
+        it in the middle of a step."""
         check(self.lib.gs_ctx_reserve(self.handle, int(n_max), int(d_max), int(result_size[0]), int(result_size[1]),
-                                      int(tile_size), int(bool(arrays))), "gs_ctx_reserve")
+                                      int(tile_size), int(bool(arrays)), int(batch_views)), "gs_ctx_reserve")
 
     def profile(self, enable=True):
         """Bracket every kernel launch with HIP events (see read_profile)."""
@@ -441,6 +442,71 @@ def bin_culled_finish(tok, want_keys=False):
                                        tok["off"], D.value, _ptr(keys), _ptr(vals), _ptr(ranges)),
               "gs_bin_fill_culled")
     return TileBinning(keys[:D.value] if want_keys else None, vals[:D.value], ranges, D.value, [W, H], ts)
+
+
+def _prepare_views(pres, records):
+    views = (_lib.GsViewPrepare * max(len(pres), 1))()
+    for k, p in enumerate(pres):
+        views[k].tiles_touched = p["rect"].data_ptr()
+        views[k].depths = p["depths"].data_ptr()
+        views[k].records = p["rec"].data_ptr() if records else None
+        views[k].perm = p["perm"].data_ptr()
+        views[k].offsets = p["offsets"].data_ptr()
+    return views
+
+
+def bin_prepare_begin(ctx, pres, result_size, tile_size, pixel_offset, culled):
+    """gs_bin_prepare_begin for the views in `pres` (records of preprocess_batch, at most 8): launches their counts on
+    the ctx's stream; every record gets "perm" and "offsets" device arrays.  Returns a token for bin_prepare_end."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    N = len(pres[0]["depths"]) if pres else 0
+    # the records only receive their perm / offsets once the call has succeeded: a refused call must not replace
+    # (and thereby free) arrays that an earlier, still pending batch is about to write
+    fresh = [dict(p, perm=torch.empty((max(N, 1),), dtype=torch.int32, device=c.device),
+                  offsets=torch.empty((max(N, 1),), dtype=torch.int32, device=c.device)) for p in pres]
+    views = _prepare_views(fresh, culled)
+    W, H, ts = int(result_size[0]), int(result_size[1]), int(tile_size)
+    check(c.lib.gs_bin_prepare_begin(c.handle, N, len(pres), views, W, H, ts, float(pixel_offset)), "gs_bin_prepare_begin")
+    for p, f in zip(pres, fresh):
+        p["perm"], p["offsets"] = f["perm"], f["offsets"]
+        p.pop("D", None)
+        p.pop("prepared", None)
+    return dict(c=c, N=N, pres=pres, views=views, W=W, H=H, ts=ts, off=float(pixel_offset), culled=bool(culled))
+
+
+def bin_prepare_end(tok):
+    """gs_bin_prepare_end: one host wait for the whole batch, then the depth sorts and scans of its views are
+    launched; every record of the batch gets "D" (its number of pairs)."""
+    c = tok["c"]
+    c.sync_stream()
+    n = len(tok["pres"])
+    D = (ctypes.c_int64 * max(n, 1))()
+    check(c.lib.gs_bin_prepare_end(c.handle, tok["N"], n, tok["views"], tok["W"], tok["H"], tok["ts"], D),
+          "gs_bin_prepare_end")
+    for k, p in enumerate(tok["pres"]):
+        p["D"] = int(D[k])
+        p["prepared"] = tok
+    return [int(D[k]) for k in range(n)]
+
+
+def bin_fill_prepared(ctx, pre, want_keys=False):
+    """gs_bin_fill_prepared: emit + tile sort + ranges of one prepared view on `ctx` (its stream must be ordered
+    behind the bin_prepare_end that produced pre["perm"] / pre["offsets"])."""
+    c = _ctx(ctx)
+    c.sync_stream()
+    tok = pre["prepared"]
+    W, H, ts, N, D = tok["W"], tok["H"], tok["ts"], tok["N"], pre["D"]
+    tiles = math.ceil(W / ts) * math.ceil(H / ts)
+    dev = c.device
+    keys = torch.empty((max(D, 1),), dtype=torch.int64, device=dev) if want_keys else None
+    vals = torch.empty((max(D, 1),), dtype=torch.int32, device=dev)
+    ranges = torch.empty((tiles, 2), dtype=torch.int32, device=dev)
+    check(c.lib.gs_bin_fill_prepared(c.handle, N, _ptr(pre["rect"]), _ptr(pre["depths"]),
+                                     _ptr(pre["rec"]) if tok["culled"] else _ptr(None), _ptr(pre["perm"]),
+                                     _ptr(pre["offsets"]), D, W, H, ts, tok["off"], _ptr(keys), _ptr(vals), _ptr(ranges)),
+          "gs_bin_fill_prepared")
+    return TileBinning(keys[:D] if want_keys else None, vals[:D], ranges, D, [W, H], ts)
 
 
 class DeviceTileBinning(TileBinning):

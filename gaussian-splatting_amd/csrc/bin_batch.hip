@@ -95,6 +95,44 @@ __global__ __launch_bounds__(256) void pairs_batch_kernel(PairsArgs a, int N, Gr
                             a.offsets[v], cap, a.pairs[v]);
 }
 
+// exact lists: tiles per gaussian from the rect alone (the count of gs_bin_count)
+__global__ __launch_bounds__(256) void rect_count_batch_kernel(PairsArgs a, int N, Grid grid) {
+    const int v = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    int x0, y0, h;
+    a.counts[v][g] = tile_count(a.rect[v][g], a.depth[v][g], grid, x0, y0, h);
+}
+
+// per view: number of pairs and the largest depth key among the gaussians that own one (partials as bounds_kernel)
+__global__ __launch_bounds__(256) void count_sum_batch_kernel(PairsArgs a, int N, ulonglong2 *__restrict__ partials) {
+    __shared__ uint32_t s_max[4];
+    __shared__ unsigned long long s_sum[4];
+    const int view = blockIdx.y;
+    const uint32_t *cn = a.counts[view];
+    const int32_t *dp = a.depth[view];
+    unsigned long long c = 0;
+    uint32_t md = 0;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < N; g += BOUND_BLOCKS * 256) {
+        const uint32_t cg = cn[g];
+        c += cg;
+        if (cg) md = max(md, (uint32_t)dp[g]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        c += __shfl_xor(c, o, 64);
+        md = max(md, (uint32_t)__shfl_xor((int)md, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = md; s_sum[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        unsigned long long sum = 0;
+        for (int w = 0; w < 4; w++) { m = max(m, s_max[w]); sum += s_sum[w]; }
+        partials[view * BOUND_BLOCKS + blockIdx.x] = make_ulonglong2(sum, m);
+    }
+}
+
 struct ScanArgs {
     const int32_t *perm[BIN_MAX_VIEWS];
     const uint32_t *counts[BIN_MAX_VIEWS];
@@ -275,7 +313,7 @@ extern "C" int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
     // the batch overwrites the per-view workspace (counts, offsets, depth order, totals): a pending
     // gs_bin_count*_begin would be answered from another view's numbers, and a later gs_bin_fill* must not pass
     // its state check against what an earlier gs_bin_count left behind
-    if (ctx->count_pending_N >= 0)
+    if (ctx->count_pending_N >= 0 || ctx->prepare_pending_views > 0)
         return gs_set_error(GS_ERR_STATE, "gs_bin_culled_batch: a gs_bin_count*_begin is pending on this ctx "
                             "(call gs_bin_count_end first, or use another ctx)");
     GS_HIP(hipSetDevice(ctx->device));
@@ -422,6 +460,173 @@ extern "C" int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
         gs_prof_scope prof_(ctx, GS_K_RANGES);
         for (int v = 0; v < nv; v++) ra.tile_keys[v] = sorted_tiles[v];
         hipLaunchKernelGGL(ranges_batch_kernel, dim3(gs_div_up((int)cap, 256), nv), dim3(256), 0, ctx->stream, ra);
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The front half of the lists of a BATCH of views -- count, depth order, scanned offsets -- in launches that cover
+// every view, so that a step needs them once, not once per view (12 short dependent launches and one host wait per
+// view otherwise, which the lanes of a training step interleave with their blend kernels).  The back half (emit,
+// tile sort, ranges: what scales with D) stays per view: gs_bin_fill_prepared on the view's own ctx / stream.
+//   gs_bin_prepare_begin  counts (box test when records are given, the rect alone otherwise), per-view totals,
+//                         copy to pinned memory, event; returns at once
+//   gs_bin_prepare_end    waits for that copy (bounded), then depth sort and scan for every view into the caller's
+//                         perm / offsets; D_host[v] = pairs of view v
+namespace {
+
+int prepare_workspace(gs_ctx *ctx, int32_t N, int nv, size_t &n4, size_t &bs4, size_t &tab4, int &scan_blocks) {
+    int rc;
+    n4 = ((size_t)(N > 0 ? N : 1) * 4 + 255) & ~(size_t)255;
+    scan_blocks = gs_div_up(N > 0 ? N : 1, SCAN_TILE);
+    bs4 = ((size_t)scan_blocks * 4 + 255) & ~(size_t)255;
+    const uint32_t nb = (uint32_t)gs_div_up(N > 0 ? N : 1, RADIX_THREADS * RADIX_ITEMS) + 1;
+    tab4 = (((size_t)RADIX_BINS * nb + RADIX_BINS) * 4 + 255) & ~(size_t)255;
+    if ((rc = gs_buf_reserve(ctx, &ctx->counts, nv * n4))) return rc;
+    if ((rc = gs_buf_reserve(ctx, &ctx->block_sums, nv * bs4))) return rc;
+    if ((rc = gs_buf_reserve(ctx, &ctx->depth_sort, nv * 4 * n4))) return rc;
+    if ((rc = gs_buf_reserve(ctx, &ctx->radix_table, nv * tab4))) return rc;
+    if ((rc = gs_buf_reserve(ctx, &ctx->total, 16 + (size_t)BIN_MAX_VIEWS * 4))) return rc;
+    const size_t part_bytes = (size_t)BIN_MAX_VIEWS * BOUND_BLOCKS * sizeof(ulonglong2);
+    if ((rc = gs_buf_reserve(ctx, &ctx->bounds, part_bytes + 2 * BIN_MAX_VIEWS * 8))) return rc;
+    return GS_OK;
+}
+
+int check_prepare(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_prepare *views, int32_t res_w, int32_t res_h,
+                  int32_t tile_size, const char *who) {
+    GS_REQUIRE(ctx, "%s: ctx is NULL", who);
+    GS_REQUIRE(N >= 0, "%s: N=%d < 0", who, N);
+    GS_REQUIRE(n_views >= 1 && n_views <= BIN_MAX_VIEWS, "%s: n_views=%d not in [1, %d]", who, n_views, BIN_MAX_VIEWS);
+    GS_REQUIRE(views, "%s: views is NULL", who);
+    GS_REQUIRE(res_w > 0 && res_h > 0 && tile_size > 0, "%s: invalid frame %dx%d tile %d", who, res_w, res_h, tile_size);
+    for (int v = 0; v < n_views; v++) {
+        GS_REQUIRE(N == 0 || (views[v].tiles_touched && views[v].depths && views[v].perm && views[v].offsets),
+                   "%s: view %d has a NULL array", who, v);
+        GS_REQUIRE(((uintptr_t)views[v].tiles_touched & 15) == 0 && ((uintptr_t)views[v].records & 15) == 0,
+                   "%s: tiles_touched and records must be 16-byte aligned", who);
+        GS_REQUIRE((views[v].records != nullptr) == (views[0].records != nullptr),
+                   "%s: either every view of a batch has records (culled lists) or none has", who);
+    }
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int gs_bin_prepare_begin(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_prepare *views, int32_t res_w,
+                                    int32_t res_h, int32_t tile_size, float pixel_offset) {
+    int rc = check_prepare(ctx, N, n_views, views, res_w, res_h, tile_size, "gs_bin_prepare_begin");
+    if (rc) return rc;
+    if (ctx->count_pending_N >= 0 || ctx->prepare_pending_views > 0)
+        return gs_set_error(GS_ERR_STATE, "gs_bin_prepare_begin: a count is already pending on this ctx");
+    GS_HIP(hipSetDevice(ctx->device));
+    ctx->packed_fresh = false;
+    ctx->bin_N = -1;
+    ctx->bin_D = -1;
+    ctx->prepare_pending_views = n_views;
+    ctx->prepare_N = N;
+    if (N == 0) return GS_OK;
+    size_t n4, bs4, tab4;
+    int scan_blocks;
+    if ((rc = prepare_workspace(ctx, N, n_views, n4, bs4, tab4, scan_blocks))) { ctx->prepare_pending_views = 0; return rc; }
+    if (!ctx->bounds_event) GS_HIP(hipEventCreateWithFlags(&ctx->bounds_event, hipEventDisableTiming));
+    const Grid grid{gs_div_up(res_w, tile_size), gs_div_up(res_h, tile_size)};
+    const CullBox cb{(float)tile_size, pixel_offset};
+    PairsArgs pa{};
+    for (int v = 0; v < n_views; v++) {
+        pa.rect[v] = reinterpret_cast<const int4 *>(views[v].tiles_touched);
+        pa.depth[v] = views[v].depths;
+        pa.rec[v] = reinterpret_cast<const float4 *>(views[v].records);
+        pa.counts[v] = (uint32_t *)((char *)ctx->counts.p + v * n4);
+    }
+    const size_t part_bytes = (size_t)BIN_MAX_VIEWS * BOUND_BLOCKS * sizeof(ulonglong2);
+    ulonglong2 *partials = (ulonglong2 *)ctx->bounds.p;
+    unsigned long long *out = (unsigned long long *)((char *)ctx->bounds.p + part_bytes);
+    {
+        gs_prof_scope prof_(ctx, GS_K_COUNT);
+        if (views[0].records)
+            hipLaunchKernelGGL(pairs_batch_kernel<false>, dim3(gs_div_up(N, 256), n_views), dim3(256), 0, ctx->stream, pa, N,
+                               grid, cb, 0u);
+        else
+            hipLaunchKernelGGL(rect_count_batch_kernel, dim3(gs_div_up(N, 256), n_views), dim3(256), 0, ctx->stream, pa, N,
+                               grid);
+        hipLaunchKernelGGL(count_sum_batch_kernel, dim3(BOUND_BLOCKS, n_views), dim3(256), 0, ctx->stream, pa, N, partials);
+        hipLaunchKernelGGL(bounds_total_kernel, dim3(n_views), dim3(BOUND_BLOCKS), 0, ctx->stream,
+                           (const ulonglong2 *)partials, out);
+    }
+    GS_HIP(hipGetLastError());
+    GS_HIP(hipMemcpyAsync(ctx->total_host + 2, out, (size_t)n_views * 16, hipMemcpyDeviceToHost, ctx->stream));
+    GS_HIP(hipEventRecord(ctx->bounds_event, ctx->stream));
+    return GS_OK;
+}
+
+extern "C" int gs_bin_prepare_end(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_prepare *views, int32_t res_w,
+                                  int32_t res_h, int32_t tile_size, int64_t *D_host) {
+    int rc = check_prepare(ctx, N, n_views, views, res_w, res_h, tile_size, "gs_bin_prepare_end");
+    if (rc) return rc;
+    GS_REQUIRE(D_host, "gs_bin_prepare_end: D_host is NULL");
+    if (ctx->prepare_pending_views != n_views || ctx->prepare_N != N)
+        return gs_set_error(GS_ERR_STATE, "gs_bin_prepare_end: no gs_bin_prepare_begin of %d views / %d gaussians is pending "
+                            "on this ctx", n_views, N);
+    ctx->prepare_pending_views = 0;
+    for (int v = 0; v < n_views; v++) D_host[v] = 0;
+    if (N == 0) return GS_OK;
+    GS_HIP(hipSetDevice(ctx->device));
+    if ((rc = gs_wait_event(ctx, ctx->bounds_event, "gs_bin_prepare_end"))) return rc;
+    uint32_t max_depth = 0;
+    for (int v = 0; v < n_views; v++) {
+        const uint64_t D = ctx->total_host[2 + 2 * v];
+        if (D >= (1ull << 31))
+            return gs_set_error(GS_ERR_ARG, "gs_bin_prepare_end: view %d has %llu pairs, beyond the 2^31-1 limit", v,
+                                (unsigned long long)D);
+        D_host[v] = (int64_t)D;
+        const uint32_t md = (uint32_t)ctx->total_host[2 + 2 * v + 1];
+        if (md > max_depth) max_depth = md;
+    }
+    size_t n4, bs4, tab4;
+    int scan_blocks;
+    if ((rc = prepare_workspace(ctx, N, n_views, n4, bs4, tab4, scan_blocks))) return rc;   // sized by _begin: no growth
+    auto at = [](gs_buf &b, size_t off) { return (char *)b.p + off; };
+    const int nv = n_views;
+    // K4a: gaussians into (u32(depth), id) order; only the bytes the batch's largest key occupies are sorted
+    int depth_bits = bits_of_u32(max_depth);
+    if (depth_bits < 1) depth_bits = 1;
+    const int depth_passes = (depth_bits + 7) / 8;
+    {
+        gs_prof_scope prof_(ctx, GS_K_DEPTH_SORT);
+        for (int p = 0; p < depth_passes; p++) {
+            const bool last = p == depth_passes - 1;
+            const int nbits = last ? depth_bits - 8 * p : 8;
+            RadixArgs a{};
+            a.n = (uint32_t)N;
+            for (int v = 0; v < nv; v++) {
+                char *ds = at(ctx->depth_sort, v * 4 * n4);
+                uint32_t *dk[2] = {(uint32_t *)ds, (uint32_t *)(ds + n4)};
+                int32_t *dv[2] = {(int32_t *)(ds + 2 * n4), (int32_t *)(ds + 3 * n4)};
+                a.io[v].keys_in = p == 0 ? reinterpret_cast<const uint32_t *>(views[v].depths) : dk[(p - 1) & 1];
+                a.io[v].vals_in = p == 0 ? nullptr : dv[(p - 1) & 1];
+                a.io[v].keys_out = last ? nullptr : dk[p & 1];
+                a.io[v].vals_out = last ? views[v].perm : dv[p & 1];     // the order lands in the caller's array
+                a.table[v] = (uint32_t *)at(ctx->radix_table, v * tab4);
+            }
+            if ((rc = radix_pass_batch(ctx, nv, a, (uint32_t)N, RADIX_SOA, 8 * p, nbits))) return rc;
+        }
+    }
+    // K2': exclusive offsets in depth order, into the caller's array
+    uint32_t *d_words = (uint32_t *)((char *)ctx->total.p + 16);
+    ScanArgs sa{};
+    for (int v = 0; v < nv; v++) {
+        sa.perm[v] = views[v].perm;
+        sa.counts[v] = (const uint32_t *)at(ctx->counts, v * n4);
+        sa.block_sums[v] = (uint32_t *)at(ctx->block_sums, v * bs4);
+        sa.offsets[v] = views[v].offsets;
+        sa.total[v] = d_words + v;
+    }
+    {
+        gs_prof_scope prof_(ctx, GS_K_SCAN);
+        hipLaunchKernelGGL(block_sums_batch_kernel, dim3(scan_blocks, nv), dim3(SCAN_THREADS), 0, ctx->stream, sa, N);
+        hipLaunchKernelGGL(scan_blocks_batch_kernel, dim3(nv), dim3(1024), 0, ctx->stream, sa, scan_blocks);
+        hipLaunchKernelGGL(offsets_batch_kernel, dim3(scan_blocks, nv), dim3(SCAN_THREADS), 0, ctx->stream, sa, N);
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

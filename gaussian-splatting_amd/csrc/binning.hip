@@ -95,7 +95,7 @@ __global__ __launch_bounds__(COUNT_BLOCKS) void count_total_kernel(const ulonglo
 __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__restrict__ perm,
                                                         const int4 *__restrict__ rect,
                                                         const int32_t *__restrict__ depth, Grid grid,
-                                                        const uint32_t *__restrict__ offsets,
+                                                        const uint32_t *__restrict__ offsets, uint32_t D,
                                                         uint2 *__restrict__ pairs) {
     __shared__ uint32_t s_first[4][64];  // exclusive prefix of counts within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
     int x0 = 0, y0 = 0, h = 1, g = 0;
     if (i < N) {
         g = perm[i];
-        cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
+        // perm may be the caller's array (gs_bin_fill_prepared): an id that is not a gaussian owns no pair
+        if ((uint32_t)g < (uint32_t)N) cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
+        else g = 0;
     }
     const uint32_t inc = wave_inclusive_scan(cnt);
     const uint32_t first = inc - cnt;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
     for (uint32_t sbase = 0; sbase < wave_total; sbase += 64) {      // wave-uniform trip count
         const int lo = (int)slot_owner(s_mark[wave], lane, cnt, first, sbase, carry);
         const uint32_t sidx = sbase + lane;
-        if (sidx < wave_total) {
+        if (sidx < wave_total && out_base + sidx < D) {     // the second test only fails for offsets of another view
             const int4 inf = s_info[wave][lo];
             const uint32_t local = sidx - s_first[wave][lo];
             const int tx = inf.x + (int)(local / (uint32_t)inf.z);
@@ -306,6 +308,8 @@ namespace {
 int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths, int32_t res_w,
                     int32_t res_h, int32_t tile_size, const float4 *rec, float pixel_offset) {
     int rc;
+    if (ctx->prepare_pending_views > 0)
+        return gs_set_error(GS_ERR_STATE, "gs_bin_count: a gs_bin_prepare_begin is pending on this ctx (its workspace is in use)");
     ctx->bin_culled = rec != nullptr;
     ctx->packed_fresh = false;    // only a gs_blend_forward that directly follows gs_bin_fill_culled may reuse the records
     ctx->bin_N = -1;
@@ -371,6 +375,63 @@ int bin_count_end(gs_ctx *ctx, int64_t *D_host) {
     return GS_OK;
 }
 
+// K3 + K4b + K5 of one view: pairs emitted in depth order (perm) at the scanned offsets, a stable sort by tile id
+// alone, tile ranges.  `ranges` has been zeroed by the caller; D > 0.
+int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depths, Grid grid, const float4 *rec,
+                  int32_t tile_size, float pixel_offset, const int32_t *perm, const uint32_t *offsets, int64_t D,
+                  uint64_t *keys, int32_t *vals, int32_t *ranges) {
+    int rc;
+    const int tiles = grid.tiles_x * grid.tiles_y;
+    const size_t d4 = ((size_t)D * 4 + 255) & ~(size_t)255;
+    int tile_bits = bits_of((uint32_t)(tiles - 1));
+    if (tile_bits == 0) tile_bits = 1;
+    const int tile_passes = (tile_bits + 7) / 8;
+    const int bits_per_pass = (tile_bits + tile_passes - 1) / tile_passes;
+    // pairs ping-pong (2 x D x 8 bytes); the last pass writes the caller's vals and the sorted tile ids for K5
+    const size_t d8 = 2 * d4;
+    if ((rc = gs_buf_reserve(ctx, &ctx->keys_tmp, 2 * d8))) return rc;
+    if ((rc = gs_buf_reserve(ctx, &ctx->vals_tmp, d4))) return rc;
+    uint2 *pp[2] = {(uint2 *)ctx->keys_tmp.p, (uint2 *)((char *)ctx->keys_tmp.p + d8)};
+    uint32_t *sorted_tiles = (uint32_t *)ctx->vals_tmp.p;
+    {
+        gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
+        if (rec) {
+            const CullBox cb{(float)tile_size, pixel_offset};
+            hipLaunchKernelGGL(culled_pairs_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm,
+                               rect, depths, grid, rec, cb, (uint32_t *)nullptr, offsets, (uint32_t)D, pp[0]);
+        } else {
+            hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm, rect,
+                               depths, grid, offsets, (uint32_t)D, pp[0]);
+        }
+    }
+    GS_HIP(hipGetLastError());
+    {
+        gs_prof_scope prof_(ctx, GS_K_SORT);
+        for (int p = 0; p < tile_passes; p++) {
+            const int shift = p * bits_per_pass;
+            const int nbits = (tile_bits - shift < bits_per_pass) ? tile_bits - shift : bits_per_pass;
+            const bool last = p == tile_passes - 1;
+            RadixIO io{};
+            io.pairs_in = pp[p & 1];
+            io.pairs_out = pp[(p & 1) ^ 1];
+            io.keys_out = sorted_tiles;
+            io.vals_out = vals;
+            if ((rc = radix_pass(ctx, (uint32_t)D, io, last ? RADIX_PAIRS_TO_SOA : RADIX_PAIRS, shift, nbits))) return rc;
+        }
+    }
+
+    {
+        gs_prof_scope prof_(ctx, GS_K_RANGES);
+        hipLaunchKernelGGL(ranges_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream, (uint32_t)D,
+                           (const uint32_t *)sorted_tiles, ranges);
+        if (keys)
+            hipLaunchKernelGGL(build_keys_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream, (uint32_t)D,
+                               (const uint32_t *)sorted_tiles, (const int32_t *)vals, depths, keys);
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths, int32_t res_w,
              int32_t res_h, int32_t tile_size, const float4 *rec, float pixel_offset, int64_t D, uint64_t *keys,
              int32_t *vals, int32_t *ranges) {
@@ -388,7 +449,7 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     if (D == 0) return GS_OK;
     GS_REQUIRE(vals, "gs_bin_fill: vals is NULL with D=%lld", (long long)D);
     const int4 *rect = reinterpret_cast<const int4 *>(tiles_touched);
-    const size_t n4 = ((size_t)N * 4 + 255) & ~(size_t)255, d4 = ((size_t)D * 4 + 255) & ~(size_t)255;
+    const size_t n4 = ((size_t)N * 4 + 255) & ~(size_t)255;
 
     // K4a: gaussians into (u32(depth), id) order; only the bytes max(depth) occupies are sorted
     if ((rc = gs_buf_reserve(ctx, &ctx->depth_sort, 4 * n4))) return rc;
@@ -430,55 +491,8 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     }
     GS_HIP(hipGetLastError());
 
-    // K3 + K4b: duplicate in depth order, then a stable sort by tile id alone
-    int tile_bits = bits_of((uint32_t)(tiles - 1));
-    if (tile_bits == 0) tile_bits = 1;
-    const int tile_passes = (tile_bits + 7) / 8;
-    const int bits_per_pass = (tile_bits + tile_passes - 1) / tile_passes;
-    // pairs ping-pong (2 x D x 8 bytes); the last pass writes the caller's vals and the sorted tile ids for K5
-    const size_t d8 = 2 * d4;
-    if ((rc = gs_buf_reserve(ctx, &ctx->keys_tmp, 2 * d8))) return rc;
-    if ((rc = gs_buf_reserve(ctx, &ctx->vals_tmp, d4))) return rc;
-    uint2 *pp[2] = {(uint2 *)ctx->keys_tmp.p, (uint2 *)((char *)ctx->keys_tmp.p + d8)};
-    uint32_t *sorted_tiles = (uint32_t *)ctx->vals_tmp.p;
-    {
-        gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
-        if (rec) {
-            const CullBox cb{(float)tile_size, pixel_offset};
-            hipLaunchKernelGGL(culled_pairs_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm,
-                               rect, depths, grid, rec, cb, (uint32_t *)nullptr, (const uint32_t *)ctx->offsets.p,
-                               (uint32_t)D, pp[0]);
-        } else {
-            hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm, rect,
-                               depths, grid, (const uint32_t *)ctx->offsets.p, pp[0]);
-        }
-    }
-    GS_HIP(hipGetLastError());
-    {
-        gs_prof_scope prof_(ctx, GS_K_SORT);
-        for (int p = 0; p < tile_passes; p++) {
-            const int shift = p * bits_per_pass;
-            const int nbits = (tile_bits - shift < bits_per_pass) ? tile_bits - shift : bits_per_pass;
-            const bool last = p == tile_passes - 1;
-            RadixIO io{};
-            io.pairs_in = pp[p & 1];
-            io.pairs_out = pp[(p & 1) ^ 1];
-            io.keys_out = sorted_tiles;
-            io.vals_out = vals;
-            if ((rc = radix_pass(ctx, (uint32_t)D, io, last ? RADIX_PAIRS_TO_SOA : RADIX_PAIRS, shift, nbits))) return rc;
-        }
-    }
-
-    {
-        gs_prof_scope prof_(ctx, GS_K_RANGES);
-        hipLaunchKernelGGL(ranges_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream, (uint32_t)D,
-                           (const uint32_t *)sorted_tiles, ranges);
-        if (keys)
-            hipLaunchKernelGGL(build_keys_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream, (uint32_t)D,
-                               (const uint32_t *)sorted_tiles, (const int32_t *)vals, depths, keys);
-    }
-    GS_HIP(hipGetLastError());
-    return GS_OK;
+    return bin_emit_sort(ctx, N, rect, depths, grid, rec, tile_size, pixel_offset, perm, (const uint32_t *)ctx->offsets.p, D,
+                         keys, vals, ranges);
 }
 
 int cull_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,
@@ -491,28 +505,34 @@ int cull_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colo
 
 // Workspace of the per-view entry points for up to N_max gaussians and D_max list entries, allocated once.
 extern "C" int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t res_w, int32_t res_h,
-                              int32_t tile_size, int32_t array_api) {
+                              int32_t tile_size, int32_t array_api, int32_t batch_views) {
     GS_REQUIRE(ctx, "gs_ctx_reserve: ctx is NULL");
     GS_REQUIRE(N_max >= 0 && D_max >= 0 && D_max < (1ll << 31), "gs_ctx_reserve: N_max=%d D_max=%lld out of range", N_max,
                (long long)D_max);
     GS_REQUIRE(res_w > 0 && res_h > 0 && tile_size > 0, "gs_ctx_reserve: invalid frame %dx%d tile %d", res_w, res_h,
                tile_size);
+    GS_REQUIRE(batch_views >= 0 && batch_views <= GS_BIN_MAX_VIEWS, "gs_ctx_reserve: batch_views=%d not in [0, %d]",
+               batch_views, GS_BIN_MAX_VIEWS);
     GS_HIP(hipSetDevice(ctx->device));
+    const size_t nv = batch_views > 1 ? (size_t)batch_views : 1;      // gs_bin_prepare_*: one slice per view
     const size_t N = (size_t)(N_max > 0 ? N_max : 1), D = (size_t)(D_max > 0 ? D_max : 1);
     const size_t n4 = (N * 4 + 255) & ~(size_t)255, d4 = (D * 4 + 255) & ~(size_t)255;
     const size_t small_tile = (size_t)RADIX_THREADS * RADIX_ITEMS;
     const size_t radix_blocks = ((N > D ? N : D) + small_tile - 1) / small_tile;       // the small tile bounds both
     const size_t blocks16 = (size_t)gs_div_up(res_w, 16) * gs_div_up(res_h, 16);
     struct { gs_buf *b; size_t bytes; } want[] = {
-        {&ctx->counts, N * 4}, {&ctx->total, 16 + COUNT_BLOCKS * sizeof(ulonglong2)}, {&ctx->depth_sort, 4 * n4},
-        {&ctx->offsets, N * 4}, {&ctx->block_sums, (size_t)gs_div_up((int)N, SCAN_TILE) * 4}, {&ctx->keys_tmp, 4 * d4},
-        {&ctx->vals_tmp, d4}, {&ctx->radix_table, ((size_t)RADIX_BINS * radix_blocks + RADIX_BINS) * 4},
+        {&ctx->counts, nv * n4}, {&ctx->total, 16 + COUNT_BLOCKS * sizeof(ulonglong2)}, {&ctx->depth_sort, nv * 4 * n4},
+        {&ctx->offsets, N * 4}, {&ctx->block_sums, nv * (((size_t)gs_div_up((int)N, SCAN_TILE) * 4 + 255) & ~(size_t)255)},
+        {&ctx->keys_tmp, 4 * d4}, {&ctx->vals_tmp, d4},
+        {&ctx->radix_table, nv * ((((size_t)RADIX_BINS * (radix_blocks + 1) + RADIX_BINS) * 4 + 255) & ~(size_t)255)},
+        {&ctx->bounds, batch_views ? (size_t)GS_BIN_MAX_VIEWS * 256 * sizeof(ulonglong2) + 2 * GS_BIN_MAX_VIEWS * 8 : 0},
         {&ctx->tile_order_buf, blocks16 * 2 * sizeof(int32_t)}, {&ctx->loss_partials, 1024 * sizeof(double)},
         {&ctx->packed, array_api ? N * 64 : 0}, {&ctx->grad_rows, array_api ? N * 64 : 0}};
     for (auto &w : want)
         if (w.bytes)
             if (const int rc = gs_buf_reserve(ctx, w.b, w.bytes, true)) return rc;
     if (!ctx->count_event) GS_HIP(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
+    if (batch_views && !ctx->bounds_event) GS_HIP(hipEventCreateWithFlags(&ctx->bounds_event, hipEventDisableTiming));
     return GS_OK;
 }
 
@@ -538,6 +558,26 @@ extern "C" int gs_bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched,
     int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
     if (rc) return rc;
     return bin_fill(ctx, N, tiles_touched, depths, res_w, res_h, tile_size, nullptr, 0.0f, D, keys, vals, ranges);
+}
+
+extern "C" int gs_bin_fill_prepared(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                                    const float *records, const int32_t *perm, const uint32_t *offsets, int64_t D,
+                                    int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset, uint64_t *keys,
+                                    int32_t *vals, int32_t *ranges) {
+    int rc = check_bin_args(ctx, N, tiles_touched, depths, res_w, res_h, tile_size);
+    if (rc) return rc;
+    GS_REQUIRE(ranges, "gs_bin_fill_prepared: ranges is NULL");
+    GS_REQUIRE(D >= 0 && D < (1ll << 31), "gs_bin_fill_prepared: D=%lld out of range", (long long)D);
+    GS_REQUIRE(((uintptr_t)records & 15) == 0, "gs_bin_fill_prepared: records must be 16-byte aligned");
+    ctx->packed_fresh = false;
+    GS_HIP(hipSetDevice(ctx->device));
+    const Grid grid{gs_div_up(res_w, tile_size), gs_div_up(res_h, tile_size)};
+    GS_HIP(hipMemsetAsync(ranges, 0, (size_t)grid.tiles_x * grid.tiles_y * 8, ctx->stream));
+    if (D == 0 || N == 0) return GS_OK;
+    GS_REQUIRE(vals && perm && offsets, "gs_bin_fill_prepared: NULL vals / perm / offsets with D=%lld", (long long)D);
+    return bin_emit_sort(ctx, N, reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
+                         reinterpret_cast<const float4 *>(records), tile_size, pixel_offset, perm, offsets, D, keys, vals,
+                         ranges);
 }
 
 extern "C" int gs_bin_count_culled_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched,

@@ -206,7 +206,9 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
     float4 geo = make_float4(0.f, 0.f, 0.f, 0.f), con = geo;
     if (i < N) {
         g = CULL_EMIT ? perm[i] : i;
-        cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
+        // perm may be the caller's array (gs_bin_fill_prepared): an id that is not a gaussian owns no pair
+        if ((uint32_t)g < (uint32_t)N) cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
+        else g = 0;
         if (cnt) {
             geo = rec[(size_t)g * 4];
             con = rec[(size_t)g * 4 + 1];

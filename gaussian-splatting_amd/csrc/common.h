@@ -68,6 +68,8 @@ struct gs_ctx {
     uint64_t *total_host = nullptr;   // pinned: 2 words (D, max depth) + 2 per view of a batch
     hipEvent_t count_event = nullptr; // recorded behind the copy of D into total_host (gs_bin_count*_begin)
     int32_t count_pending_N = -1;     // N of a gs_bin_count*_begin whose gs_bin_count_end has not run
+    int32_t prepare_pending_views = 0;   // views of a gs_bin_prepare_begin whose gs_bin_prepare_end has not run
+    int32_t prepare_N = -1;
     // state carried from gs_bin_count to gs_bin_fill
     bool prof_on = false;
     uint32_t prof_mask = 0xFFFFFFFFu;         // kernel ids that are timed when prof_on (option profile_mask)

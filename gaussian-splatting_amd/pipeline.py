@@ -122,7 +122,9 @@ class SplatPipeline:
         self.lanes(n - 1 if n > 3 else n)
         self.alt_contexts(n)
         for c in self.contexts():
-            c.reserve(n_max, d_max, self.result_size, self.tile_size)
+            # the first two alternates hold the batches of gs_bin_prepare_* that a step keeps in flight
+            batch = 8 if any(c is a for a in self._alts[:2]) else 0
+            c.reserve(n_max, d_max, self.result_size, self.tile_size, batch_views=batch)
 
     def workspace_bytes(self):
         return sum(c.info("workspace_bytes") for c in self.contexts())
@@ -417,6 +419,79 @@ def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, sca
     return states, done, lanes
 
 
+def _render_prepared(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale):
+    """The same work as _render_on_lanes with the front half of every view's lists -- count, depth order, scanned
+    offsets -- done per BATCH of views on the main stream (gs_bin_prepare_begin / _end: a dozen launches and one host
+    wait per batch instead of per view) and only what scales with the number of pairs -- emit, tile sort, ranges
+    (gs_bin_fill_prepared) -- on the view's lane, in front of its blend kernels.  The first batch is the first view of
+    every lane, so the lanes start after one short K1; the second batch (the rest, up to 8 views) is projected and
+    counted under the first views' blends.  Returns (states, done events per view, lanes)."""
+    main = pipe.ctx.current_stream()
+    if n_lanes > 3:
+        lanes = pipe.lanes(n_lanes - 1) + [(pipe.ctx, main)]
+    else:
+        lanes = pipe.lanes(n_lanes)
+    prep = pipe.alt_contexts(2)          # workspaces of the batches in flight; both launch on the main stream
+    first = min(n_lanes, len(mine))
+    groups = [list(range(first))] + [list(range(g0, min(g0 + 8, len(mine)))) for g0 in range(first, len(mine), 8)]
+    pres, toks, ready = {}, {}, {}
+    group_of = {k: gi for gi, g in enumerate(groups) for k in g}
+
+    def start(gi):
+        ks = groups[gi]
+        for k, p in zip(ks, pipe.preprocess_batch([views[mine[k]] for k in ks])):
+            pres[k] = p
+        toks[gi] = api.bin_prepare_begin(prep[gi % 2], [pres[k] for k in ks], pipe.result_size, pipe.tile_size,
+                                         pipe.pixel_offset, pipe.cull_tiles)
+
+    def finish(gi):
+        api.bin_prepare_end(toks.pop(gi))           # the one host wait of the batch
+        ready[gi] = main.record_event()
+
+    start(0)
+    finish(0)
+    if len(groups) > 1:
+        start(1)                                    # K1 + counts of the later views, behind the first batch's sorts
+
+    def advance():
+        """Finishes the batch whose counts are in flight and starts the one after it.  Its sorts and scans go onto the
+        main stream, so this runs BEFORE the main stream receives a view's blend kernels (about a millisecond of
+        work that the other lanes' next views would otherwise wait behind)."""
+        for gi in sorted(toks):
+            finish(gi)
+            if gi + 1 < len(groups) and gi + 1 not in ready:
+                start(gi + 1)
+
+    states, done = [], []
+    for r0 in range(0, len(mine), n_lanes):
+        # side lanes first, the main stream's view last
+        ks = sorted(range(r0, min(r0 + n_lanes, len(mine))), key=lambda k: (lanes[k % n_lanes][1] is main, k))
+        fwd = {}
+        for k in ks:
+            ctx, stream = lanes[k % n_lanes]
+            if stream is main:
+                advance()
+            while group_of[k] not in ready:         # more than two batches: the later ones start as the earlier finish
+                if not toks:
+                    start(min(g for g in range(len(groups)) if g not in ready))
+                advance()
+            with pipe.ctx.use_stream(stream):
+                stream.wait_event(ready[group_of[k]])
+                with _records(ctx, pipe.N, pres[k].get("rec")):
+                    b = api.bin_fill_prepared(ctx, pres[k])
+                fwd[k] = pipe.forward_blend(dict(pre=pres[k], opac=pres[k]["opac"], binning=b, c=ctx))
+        ks = sorted(ks)
+        for k in ks:
+            stream = lanes[k % n_lanes][1]
+            image, state = fwd[k]
+            with pipe.ctx.use_stream(stream):
+                dL, _ = pipe.image_loss(image, targets[mine[k]], loss_kind, scale, losses[k:k + 1], ctx=state["ctx"])
+                pipe.backward_rows(state, dL)
+                done.append(stream.record_event())
+            states.append(state)
+    return states, done, lanes
+
+
 def _render_batched(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale, group):
     """The same work as _render_on_lanes with the lists of `group` views built per batch of launches on the main
     stream (gs_bin_culled_batch: no per-view host wait, about 20 launches per group instead of 25 per view) and the
@@ -491,7 +566,7 @@ def auto_lanes(pipe):
 
 
 def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,
-               k8_early_lanes=None, allreduce_chunks=4, batch_binning=False, bin_group=4):
+               k8_early_lanes=None, allreduce_chunks=4, batch_binning=False, bin_group=4, prepared=False):
     """Forward+backward over this rank's shard of `views`, then the all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
@@ -506,7 +581,12 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     launches with no per-view host wait (gs_bin_culled_batch; one wait per step for the bounds) -- measured on
     MI355X it does not pay at 1080p / 1M (6.18 ms per 8-view step against 5.92 ms: the batched sorts are 25 %
     cheaper alone, but the step loses the overlap of one view's sorts with another's blends), so the default is
-    the per-view path.  Returns (sum of local losses as a device scalar, number of local views)."""
+    the per-view path.  prepared=True: the count, depth order and scanned offsets of the views are built per batch of
+    views on the main stream (gs_bin_prepare_begin / _end) and only emit + tile sort + ranges run on the view's lane
+    (_render_prepared); False (default): every view builds its lists on its lane (_render_on_lanes).  Measured on
+    MI355X at 1 M / 1080p / 8 views: 6.02-6.13 ms per step prepared (and 7.9 ms in some launch arrangements: the
+    main stream then carries the batches' sorts AND a lane's blends) against 5.85-5.89 ms per view, so it is off.
+    Returns (sum of local losses as a device scalar, number of local views)."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
@@ -539,7 +619,8 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
                 main.wait_stream(stream)
     elif n_lanes > 1:
         main = pipe.ctx.current_stream()
-        states, done, lanes = _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale)
+        render = _render_prepared if prepared else _render_on_lanes
+        states, done, lanes = render(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale)
         # The lanes do not finish together (the hardware serves the queues in a fixed order): K8 of the
         # early lanes' views runs on lane 0's stream while the others still blend.
         if k8_early_lanes is None:

@@ -64,10 +64,11 @@ int64_t gs_ctx_info(gs_ctx *ctx, const char *name);
  * what a training loop with a growing gaussian count (BASELINE configs[3]) would otherwise pay after every
  * densification.  array_api != 0 also reserves the packed records and gradient rows that the array-based entry
  * points keep (64 bytes per gaussian each); callers that hand over records and rows (gs_ctx_use_records,
- * gs_blend_backward_rows) pass 0.  The ordered K7 reduction's buffers (option deterministic_backward) are not
- * covered.  About 20 bytes per gaussian + 20 bytes per list entry. */
+ * gs_blend_backward_rows) pass 0.  batch_views > 0 also sizes the ctx for gs_bin_prepare_begin / _end batches of that
+ * many views (24 more bytes per gaussian and view).  The ordered K7 reduction's buffers (option
+ * deterministic_backward) are not covered.  About 28 bytes per gaussian + 20 bytes per list entry. */
 int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t res_w, int32_t res_h, int32_t tile_size,
-                   int32_t array_api);
+                   int32_t array_api, int32_t batch_views);
 /* Tuning knobs (no reference counterpart).  "pixels_per_thread": 1, 2 or 4 pixels of a tile
  * column per thread in the blend kernels (default 4 = one wavefront per 16x16 tile; also read
  * from the environment variable GSPLAT_PPT at ctx creation).
@@ -221,6 +222,38 @@ int gs_bin_bounds_batch(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_b
                         int32_t res_h, int32_t tile_size, int64_t *bounds_host);
 int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_bin *views, int32_t res_w,
                         int32_t res_h, int32_t tile_size, float pixel_offset, int32_t depth_bits, int64_t capacity);
+
+/* The lists of a batch of views in two halves (no counterpart in the reference, which builds one view's lists at a
+ * time on the host: rasterization.py:6-25,57-71).  What does not scale with the number of pairs -- the count, the
+ * depth order of the gaussians, the scanned offsets -- is done for up to GS_BIN_MAX_VIEWS views by launches that
+ * each cover every view (about 12 launches per BATCH and one host wait, instead of 12 short dependent launches
+ * and one host wait per VIEW); what does -- emitting the pairs, the tile sort, the ranges -- stays per view, so
+ * that the views of a training step can run it on their own streams next to other views' blend kernels.
+ *   gs_bin_prepare_begin   launches the counts (records != NULL: the culled count of gs_bin_count_culled; NULL: the
+ *                          rect count of gs_bin_count; the same for every view of a batch) and the copy of the
+ *                          per-view totals to pinned memory; returns at once.  One batch may be pending per ctx.
+ *   gs_bin_prepare_end     waits for that copy only (bounded, as gs_bin_count_end), then launches the depth sort and
+ *                          the scan of every view; perm[N] (gaussians in (u32(depth), id) order) and offsets[N]
+ *                          (exclusive prefix of pairs in that order) are caller-owned DEVICE arrays;
+ *                          D_host[v] = pairs of view v.
+ *   gs_bin_fill_prepared   K3 + K4b + K5 of ONE view from its perm / offsets / D, on any ctx of the device, stream-
+ *                          ordered behind gs_bin_prepare_end by the caller: the result is bit for bit that of
+ *                          gs_bin_fill (records == NULL) or gs_bin_fill_culled (records given). */
+typedef struct {
+    const int32_t *tiles_touched;   /* [N,4]  */
+    const int32_t *depths;          /* [N]    */
+    const float *records;           /* [N,16] or NULL */
+    int32_t *perm;                  /* [N] out */
+    uint32_t *offsets;              /* [N] out */
+} gs_view_prepare;
+int gs_bin_prepare_begin(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_prepare *views, int32_t res_w,
+                         int32_t res_h, int32_t tile_size, float pixel_offset);
+int gs_bin_prepare_end(gs_ctx *ctx, int32_t N, int32_t n_views, const gs_view_prepare *views, int32_t res_w,
+                       int32_t res_h, int32_t tile_size, int64_t *D_host);
+int gs_bin_fill_prepared(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths,
+                         const float *records, const int32_t *perm, const uint32_t *offsets, int64_t D,
+                         int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset, uint64_t *keys,
+                         int32_t *vals, int32_t *ranges);
 
 /* Replaces gpu_rasterize forward (rasterization.py:27-107 + kernel rasterize,
  * setup_gpu.py:46-100), c_rasterize/rasterize_tile (rasterization.py:109-153, rasterize.c:27-132)

@@ -70,6 +70,18 @@ class FakeLib:
     def gs_bin_fill_culled(self, h, *a):
         return 0
 
+    def gs_bin_prepare_begin(self, h, n, n_views, views, *a):
+        self.log.append(("prepare", n_views))
+        return 0
+
+    def gs_bin_prepare_end(self, h, n, n_views, views, w, hh, ts, D):
+        for k in range(n_views):
+            D[k] = 7
+        return 0
+
+    def gs_bin_fill_prepared(self, h, *a):
+        return 0
+
     def gs_bin_bounds_batch(self, h, n, n_views, views, w, hh, ts, out):
         for k in range(n_views):
             out[2 * k], out[2 * k + 1] = 7, 1000

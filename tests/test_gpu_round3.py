@@ -187,3 +187,30 @@ def test_workspace_accounting(gpu_ctx):
     with pytest.raises(gs.GsError):
         c.info("nonsense")
     c.close()
+
+
+@pytest.mark.parametrize("culled", [False, True])
+@pytest.mark.parametrize("W,H,tile", [(640, 360, 16), (203, 117, 32)])
+def test_prepared_batch_lists_equal_the_per_view_calls(gpu_ctx, culled, W, H, tile):
+    """gs_bin_prepare_begin / _end + gs_bin_fill_prepared (count, depth order and offsets per batch of views; emit,
+    tile sort and ranges per view, here on another ctx) against gs_bin_count[_culled] + gs_bin_fill[_culled] view by
+    view: D, keys, values and ranges bit for bit, for the reference's lists and the culled ones."""
+    import torch
+    import gsplat_amd as gs
+    from bench import make_views
+    cam, R, t, g, rs = synth_scene(50_000, W, H, seed=23, log_scale=(0.5, 3.0))
+    pipe = gs.SplatPipeline(g, rs, tile_size=tile, opacity_is_logit=False, ctx=gpu_ctx, cull_tiles=culled)
+    views = make_views(gs, cam, 5)
+    pres = pipe.preprocess_batch(views)
+    other = gpu_ctx.clone()
+    tok = gs.api.bin_prepare_begin(other, pres, rs, tile, pipe.pixel_offset, culled)
+    with pytest.raises(gs.GsError, match="pending"):
+        gs.api.bin_prepare_begin(other, pres, rs, tile, pipe.pixel_offset, culled)     # one batch per ctx
+    Ds = gs.api.bin_prepare_end(tok)
+    for k, p in enumerate(pres):
+        ref = pipe.forward_bin(pipe.forward_begin(views[k], pre=p), want_keys=True)
+        with pipe_records(gs, gpu_ctx, pipe.N, p["rec"]):
+            got = gs.api.bin_fill_prepared(gpu_ctx, p, want_keys=True)
+        assert Ds[k] == got.D == ref.D > 0
+        assert torch.equal(got.ranges, ref.ranges) and torch.equal(got.vals, ref.vals) and torch.equal(got.keys, ref.keys)
+    other.close()
