@@ -34,6 +34,7 @@ namespace {
 // that emit anything (it decides how many depth-sort passes are needed).  COUNT_BLOCKS blocks
 // grid-stride over N; count_total_kernel folds the partials (no same-address atomics).
 constexpr int COUNT_BLOCKS = 1024;
+constexpr int TILE_HIST_MAX = 32768;     // tile ids whose counters fit one workgroup's LDS (128 KiB of the CU's 160)
 
 __global__ __launch_bounds__(SCAN_THREADS) void count_kernel(int N, const int4 *__restrict__ rect,
                                                              const int32_t *__restrict__ depth, Grid grid,
@@ -190,6 +191,17 @@ __global__ __launch_bounds__(THREADS) void radix_hist_kernel(uint32_t n, const u
                                                              uint32_t nblocks, uint32_t *__restrict__ table) {
     radix2_hist_body<THREADS, RADIX_ITEMS, PAIRS>(blockIdx.x, n, keys, pairs, shift, mask, nblocks, table);
 }
+template <int ITEMS_PER_1024>
+__global__ __launch_bounds__(1024) void tile_hist_kernel(uint32_t n, const uint2 *__restrict__ pairs, uint32_t mask,
+                                                         uint32_t nblocks, uint32_t *__restrict__ table, uint32_t ntiles,
+                                                         uint32_t *__restrict__ tile_counts) {
+    extern __shared__ uint32_t s_tiles_dyn[];
+    radix2_hist_tiles_body<1024, ITEMS_PER_1024>(n, pairs, mask, nblocks, table, ntiles, tile_counts, s_tiles_dyn);
+}
+__global__ __launch_bounds__(1024) void ranges_from_counts_kernel(uint32_t ntiles, const uint32_t *__restrict__ tile_counts,
+                                                                  int32_t *__restrict__ ranges) {
+    ranges_from_counts_body(ntiles, tile_counts, ranges);
+}
 __global__ __launch_bounds__(SCAN_THREADS) void radix_scan_kernel(uint32_t nblocks, uint32_t *__restrict__ table,
                                                                   uint32_t *__restrict__ totals) {
     radix_scan_body(blockIdx.x, nblocks, table, totals);
@@ -227,8 +239,10 @@ int check_bin_args(gs_ctx *ctx, int32_t N, const int32_t *rect, const int32_t *d
 }
 
 // one stable LSD pass over n elements on ctx->stream; `mode` says where they come from and go to (RadixMode)
+// tile_counts != NULL (first pass of a tile sort, shift == 0): the histogram kernel also counts the pairs per tile id
 template <int THREADS>
-int radix_pass_t(gs_ctx *ctx, uint32_t n, const RadixIO &io, int mode, int shift, int nbits) {
+int radix_pass_t(gs_ctx *ctx, uint32_t n, const RadixIO &io, int mode, int shift, int nbits, uint32_t ntiles = 0,
+                 uint32_t *tile_counts = nullptr) {
     constexpr int TILE = THREADS * RADIX_ITEMS;
     const uint32_t nblocks = (n + TILE - 1) / TILE;
     int rc;
@@ -236,7 +250,18 @@ int radix_pass_t(gs_ctx *ctx, uint32_t n, const RadixIO &io, int mode, int shift
     uint32_t *totals = (uint32_t *)ctx->radix_table.p;
     uint32_t *table = totals + RADIX_BINS;
     const uint32_t mask = (1u << nbits) - 1u;
-    if (mode == RADIX_SOA)
+    if (tile_counts) {
+        // one workgroup per CU (its LDS holds the whole tile histogram), blocks of this pass's scatter size
+        const uint32_t grid = nblocks < 256u ? nblocks : 256u;
+        static bool lds_allowed = false;     // above 64 KiB of dynamic LDS the kernel has to be told so once
+        if (!lds_allowed) {
+            GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_hist_kernel<THREADS * RADIX_ITEMS / 1024>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TILE_HIST_MAX * 4));
+            lds_allowed = true;
+        }
+        hipLaunchKernelGGL((tile_hist_kernel<THREADS * RADIX_ITEMS / 1024>), dim3(grid), dim3(1024), (size_t)ntiles * 4,
+                           ctx->stream, n, io.pairs_in, mask, nblocks, table, ntiles, tile_counts);
+    } else if (mode == RADIX_SOA)
         hipLaunchKernelGGL((radix_hist_kernel<THREADS, false>), dim3(nblocks), dim3(THREADS), 0, ctx->stream, n, io.keys_in,
                            (const uint2 *)nullptr, shift, mask, nblocks, table);
     else
@@ -262,9 +287,10 @@ int radix_pass_t(gs_ctx *ctx, uint32_t n, const RadixIO &io, int mode, int shift
     return GS_OK;
 }
 
-int radix_pass(gs_ctx *ctx, uint32_t n, const RadixIO &io, int mode, int shift, int nbits) {
-    return n >= RADIX_BIG_FROM ? radix_pass_t<RADIX_THREADS_BIG>(ctx, n, io, mode, shift, nbits)
-                               : radix_pass_t<RADIX_THREADS>(ctx, n, io, mode, shift, nbits);
+int radix_pass(gs_ctx *ctx, uint32_t n, const RadixIO &io, int mode, int shift, int nbits, uint32_t ntiles = 0,
+               uint32_t *tile_counts = nullptr) {
+    return n >= RADIX_BIG_FROM ? radix_pass_t<RADIX_THREADS_BIG>(ctx, n, io, mode, shift, nbits, ntiles, tile_counts)
+                               : radix_pass_t<RADIX_THREADS>(ctx, n, io, mode, shift, nbits, ntiles, tile_counts);
 }
 
 RadixIO soa_io(const uint32_t *keys_in, const int32_t *vals_in, uint32_t *keys_out, int32_t *vals_out) {
@@ -393,6 +419,15 @@ int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depth
     if ((rc = gs_buf_reserve(ctx, &ctx->vals_tmp, d4))) return rc;
     uint2 *pp[2] = {(uint2 *)ctx->keys_tmp.p, (uint2 *)((char *)ctx->keys_tmp.p + d8)};
     uint32_t *sorted_tiles = (uint32_t *)ctx->vals_tmp.p;
+    // K5 from a per-tile histogram taken in the first pass, when it fits one workgroup's LDS and nobody wants the
+    // sorted tile ids (the 64-bit keys are built from them): the last pass then writes the gaussian ids only
+    const bool hist_ranges = !keys && tiles <= TILE_HIST_MAX && ctx->tile_hist;
+    uint32_t *tile_counts = nullptr;
+    if (hist_ranges) {
+        if ((rc = gs_buf_reserve(ctx, &ctx->tile_counts, (size_t)tiles * 4))) return rc;
+        tile_counts = (uint32_t *)ctx->tile_counts.p;
+        GS_HIP(hipMemsetAsync(tile_counts, 0, (size_t)tiles * 4, ctx->stream));
+    }
     {
         gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
         if (rec) {
@@ -414,12 +449,21 @@ int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depth
             RadixIO io{};
             io.pairs_in = pp[p & 1];
             io.pairs_out = pp[(p & 1) ^ 1];
-            io.keys_out = sorted_tiles;
+            io.keys_out = hist_ranges ? nullptr : sorted_tiles;
             io.vals_out = vals;
-            if ((rc = radix_pass(ctx, (uint32_t)D, io, last ? RADIX_PAIRS_TO_SOA : RADIX_PAIRS, shift, nbits))) return rc;
+            if ((rc = radix_pass(ctx, (uint32_t)D, io, last ? RADIX_PAIRS_TO_SOA : RADIX_PAIRS, shift, nbits, (uint32_t)tiles,
+                                 p == 0 ? tile_counts : nullptr)))
+                return rc;
         }
     }
 
+    if (hist_ranges) {
+        gs_prof_scope prof_(ctx, GS_K_RANGES);
+        hipLaunchKernelGGL(ranges_from_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, (uint32_t)tiles,
+                           (const uint32_t *)tile_counts, ranges);
+        GS_HIP(hipGetLastError());
+        return GS_OK;
+    }
     {
         gs_prof_scope prof_(ctx, GS_K_RANGES);
         hipLaunchKernelGGL(ranges_kernel, dim3(gs_div_up((int)D, 256)), dim3(256), 0, ctx->stream, (uint32_t)D,
@@ -526,7 +570,8 @@ extern "C" int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t
         {&ctx->keys_tmp, 4 * d4}, {&ctx->vals_tmp, d4},
         {&ctx->radix_table, nv * ((((size_t)RADIX_BINS * (radix_blocks + 1) + RADIX_BINS) * 4 + 255) & ~(size_t)255)},
         {&ctx->bounds, batch_views ? (size_t)GS_BIN_MAX_VIEWS * 256 * sizeof(ulonglong2) + 2 * GS_BIN_MAX_VIEWS * 8 : 0},
-        {&ctx->tile_order_buf, blocks16 * 2 * sizeof(int32_t)}, {&ctx->loss_partials, 1024 * sizeof(double)},
+        {&ctx->tile_order_buf, blocks16 * 2 * sizeof(int32_t)},
+        {&ctx->tile_counts, (size_t)gs_div_up(res_w, tile_size) * gs_div_up(res_h, tile_size) * 4}, {&ctx->loss_partials, 1024 * sizeof(double)},
         {&ctx->packed, array_api ? N * 64 : 0}, {&ctx->grad_rows, array_api ? N * 64 : 0}};
     for (auto &w : want)
         if (w.bytes)

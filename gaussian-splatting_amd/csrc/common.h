@@ -80,6 +80,8 @@ struct gs_ctx {
     bool tile_order = true;           // option tile_order: blend kernels take their tiles heaviest first
     int tile_order_min = 2048, tile_order_max = 16384;   // ... for frames with this many 16x16 blocks
     gs_buf tile_order_buf;            // i32[ntiles] launch order + i32[ntiles] work per tile
+    gs_buf tile_counts;               // u32[tiles] pairs per tile (first pass of the tile sort -> K5)
+    bool tile_hist = true;            // option tile_histogram: K5 from that histogram instead of the sorted tile ids
     int32_t bin_N = -1;
     int64_t bin_D = -1;
     uint32_t bin_max_depth = 0;

@@ -127,6 +127,11 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
         ctx->tile_order = value != 0;
         return GS_OK;
     }
+    if (strcmp(name, "tile_histogram") == 0) {
+        GS_REQUIRE(value == 0 || value == 1, "tile_histogram must be 0 or 1 (got %d)", value);
+        ctx->tile_hist = value != 0;
+        return GS_OK;
+    }
     if (strcmp(name, "profile_mask") == 0) {   // bit i: time kernel id i (gs_profile_kernel_name) when profiling is on
         ctx->prof_mask = (uint32_t)value;
         return GS_OK;
@@ -223,7 +228,7 @@ extern "C" int gs_ctx_destroy(gs_ctx *ctx) {
     gs_buf *bufs[] = {&ctx->counts, &ctx->offsets, &ctx->block_sums, &ctx->total, &ctx->depth_sort,
                       &ctx->keys_tmp, &ctx->vals_tmp, &ctx->radix_table, &ctx->packed, &ctx->grad_rows,
                       &ctx->tile_scratch, &ctx->loss_partials, &ctx->stats_words, &ctx->det_partials, &ctx->det_sort,
-                      &ctx->tile_order_buf, &ctx->bounds};
+                      &ctx->tile_order_buf, &ctx->bounds, &ctx->tile_counts};
     for (gs_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (gs_prof_span &sp : ctx->prof_spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }

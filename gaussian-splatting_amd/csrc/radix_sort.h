@@ -85,6 +85,90 @@ __device__ __forceinline__ void radix2_hist_body(uint32_t slot, uint32_t n, cons
     for (int c = threadIdx.x; c < RADIX_BINS; c += THREADS) table[(size_t)c * nblocks + bid] = h[c];
 }
 
+// First pass of the tile sort, with the per-TILE histogram folded in: besides the [digit][block] table of the pass
+// a workgroup counts its pairs per tile id in LDS (up to 32 768 tiles = 128 KiB: a workgroup may hold all of a CU's
+// 160 KiB) and adds the counts to tile_counts[] once, at its end.  The exclusive scan of those counts IS the tile
+// ranges (K5), so the last pass need not write the sorted tile ids and no kernel has to read them back: 8 bytes per
+// pair less.  Persistent: `gridDim.x` workgroups walk the blocks with a stride; THREADS = 1024 keeps 16 waves on
+// the CU that the one resident workgroup occupies.
+template <int THREADS, int ITEMS>
+__device__ __forceinline__ void radix2_hist_tiles_body(uint32_t n, const uint2 *__restrict__ pairs, uint32_t mask,
+                                                       uint32_t nblocks, uint32_t *__restrict__ table, uint32_t ntiles,
+                                                       uint32_t *__restrict__ tile_counts, uint32_t *s_tiles) {
+    constexpr int TILE = THREADS * ITEMS;        // the block size of the pass's scatter kernel
+    __shared__ uint32_t h[RADIX_BINS];
+    for (uint32_t c = threadIdx.x; c < ntiles; c += THREADS) s_tiles[c] = 0u;
+    for (uint32_t slot = blockIdx.x; slot < nblocks; slot += gridDim.x) {
+        for (int c = threadIdx.x; c < RADIX_BINS; c += THREADS) h[c] = 0;
+        __syncthreads();
+        const uint32_t bid = radix_logical_block(slot, nblocks);
+        const uint32_t base = bid * (uint32_t)TILE;
+        const uint4 *p4 = reinterpret_cast<const uint4 *>(pairs + base);     // two pairs per 16-byte load
+#pragma unroll
+        for (int k = 0; k < ITEMS / 2; k++) {
+            const uint32_t e = (k * THREADS + threadIdx.x) * 2u, i = base + e;
+            if (i + 1 < n) {
+                const uint4 v = p4[k * THREADS + threadIdx.x];
+                atomicAdd(&h[v.x & mask], 1u);
+                atomicAdd(&h[v.z & mask], 1u);
+                if (v.x < ntiles) atomicAdd(&s_tiles[v.x], 1u);
+                if (v.z < ntiles) atomicAdd(&s_tiles[v.z], 1u);
+            } else if (i < n) {
+                const uint32_t key = pairs[i].x;
+                atomicAdd(&h[key & mask], 1u);
+                if (key < ntiles) atomicAdd(&s_tiles[key], 1u);
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < RADIX_BINS; c += THREADS) table[(size_t)c * nblocks + bid] = h[c];
+        __syncthreads();
+    }
+    for (uint32_t c = threadIdx.x; c < ntiles; c += THREADS) {
+        const uint32_t v = s_tiles[c];
+        if (v) atomicAdd(&tile_counts[c], v);
+    }
+}
+
+// K5 from the per-tile counts: ranges[t] = [start, start + count) with start = pairs in tiles before t; tiles
+// without pairs keep (0, 0), as the reference's lists have it.  One 1024-thread workgroup.
+__device__ __forceinline__ void ranges_from_counts_body(uint32_t ntiles, const uint32_t *__restrict__ tile_counts,
+                                                        int32_t *__restrict__ ranges) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += 1024u * 4u) {
+        uint32_t c[4], sum = 0;
+        const uint32_t t0 = base + threadIdx.x * 4u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c[k] = t0 + k < ntiles ? tile_counts[t0 + k] : 0u;
+            sum += c[k];
+        }
+        const uint32_t inc = wave_inclusive_scan(sum);
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, chunk = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) wbase += s_wave[w];
+            chunk += s_wave[w];
+        }
+        uint32_t run = s_carry + wbase + inc - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (t0 + k < ntiles) {
+                ranges[2 * (t0 + k)] = c[k] ? (int32_t)run : 0;
+                ranges[2 * (t0 + k) + 1] = c[k] ? (int32_t)(run + c[k]) : 0;
+            }
+            run += c[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += chunk;
+        __syncthreads();
+    }
+}
+
 // one 256-thread workgroup per digit: table[d][b] <- elements with digit d in blocks before b; totals[d] <- elements
 // with digit d.  (No atomics: thousands of same-address atomics serialise at ~12 ns each.)
 __device__ __forceinline__ void radix_scan_body(int bid, uint32_t nblocks, uint32_t *__restrict__ table,

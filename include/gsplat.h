@@ -80,7 +80,10 @@ int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t res_w, int
  * 48 bytes of workspace per list entry.  tile_size 16 or 32 only; one-wave-per-tile kernels only.
  * "tile_order": 1 (default; also GSPLAT_TILE_ORDER) = gs_blend_backward* hand their launch slots to the
  * 16x16 blocks heaviest-first (by the deepest last-contributor of the block, from n_contrib), for frames
- * of 2048..16384 blocks; results are unchanged (float atomics arrive in another order). */
+ * of 2048..16384 blocks; results are unchanged (float atomics arrive in another order).
+ * "tile_histogram": 1 (default) = gs_bin_fill* take the tile ranges from a per-tile histogram counted in the first
+ * pass of the tile sort (frames of up to 32 768 tiles, keys == NULL) instead of writing the sorted tile ids and
+ * reading them back; 0 = always the latter.  Same ranges bit for bit. */
 int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value);
 /* Per-kernel timing with HIP events on the ctx stream (no reference counterpart; the reference
  * only prints perf_counter deltas per stage, train.py:29-60).  While enabled every kernel launch
