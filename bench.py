@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_SUMMARY = "r03_pmc_summary.json"
 # stages whose launch is several kernels: the counters of the stage are the sums over its parts
-PMC_PARTS = {"bin_sort": ("tile_hist", "tile_scan", "tile_scatter")}
+PMC_PARTS = {"bin_sort": ("tile_hist", "tile_hist2", "tile_scatter")}     # (+ the 256-block scans, not separable by name)
 LISTS_NOTE = {
     "exact": "SplatPipeline(cull_tiles=False): the reference's own (tile, depth) lists -- keys, values and ranges "
              "bit-exact against the reference",
@@ -410,6 +410,23 @@ def main():
                                   f"OpenMP over tiles, built with gcc -O2 -fopenmp -ffp-contract=off (no -march=native: "
                                   f"oracle/Makefile), {cpu_s:.2f} s wall on {int(used)} threads; host has "
                                   f"{os.cpu_count()} logical CPUs"}
+        # the same work on the GPU, for a like-for-like reading (the headline is fwd+bwd of the whole path, this
+        # baseline is the forward blend alone): K6 on the reference's lists, alone on the chip
+        k6_ms = None
+        if args.lists == "exact" and "blend_forward" in single:
+            k6_ms = single["blend_forward"]["ms_per_launch"]
+        else:
+            exact.ctx.profile(True)
+            exact.ctx.read_profile()
+            for _ in range(3):
+                exact.forward(views[0])
+            pr = exact.ctx.read_profile().get("blend_forward")
+            exact.ctx.profile(False)
+            k6_ms = pr[0] / pr[1] if pr and pr[1] else None
+        if k6_ms:
+            cpu_baseline["gpu_same_work"] = {"what": "forward blend (K6) of one view on the same lists, alone on the chip",
+                                             "ms_per_view": round(k6_ms, 4), "value": round(P / 1e6 / (k6_ms / 1e3), 1),
+                                             "unit": "Mpix/s (forward blend only)"}
 
     if rank == 0:
         res = "%dx%d" % (W, H)

@@ -12,8 +12,8 @@ import gsplat_amd as gs
 from bench import make_scene, make_views
 
 N = int(os.environ.get("GS_N", 1_000_000))
-W, H = 1920, 1080
-g, cam = make_scene(N, W, H, (1.0, 3.0))
+W, H = int(os.environ.get("GS_W", 1920)), int(os.environ.get("GS_H", 1080))
+g, cam = make_scene(N, W, H, (float(os.environ.get("GS_LS0", 1.0)), float(os.environ.get("GS_LS1", 3.0))))
 ctx, _, _ = gs.setup_gpu(0)
 LISTS = os.environ.get("GS_LISTS", "exact")     # bench.py's default: the reference's own lists
 pipe = gs.SplatPipeline(g, [W, H], ctx=ctx, cull_tiles=LISTS == "culled")

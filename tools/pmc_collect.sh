@@ -1,8 +1,8 @@
 #!/bin/bash
 # Counter passes over tools/one_view.py (single stream, GS_VIEWS views of the bench scene), one rocprofv3 --pmc
 # run per pass (at most 8 SQ_, 4 TCC_ (FETCH_SIZE takes 3, WRITE_SIZE 2), 2 GRBM_ counters each), then the
-# kernel trace with --stats.  Run on the GPU box from the repo root:  bash tools/pmc_collect.sh gpurun_out/pmc_r02
-# Fold with: python tools/pmc_summary.py profiles/r02_pmc_summary.json <out>/p1 <out>/p2 <out>/p3 <out>/p4
+# kernel trace with --stats.  Run on the GPU box from the repo root:  bash tools/pmc_collect.sh gpurun_out/pmc_r03   (GS_LISTS=exact|culled, GS_N / GS_W / GS_H / GS_LS0 / GS_LS1 select the workload)
+# Fold with: python tools/pmc_summary.py profiles/r03_pmc_summary.json <out>/p1 <out>/p2 <out>/p3 <out>/p4
 set -e
 OUT=${1:-gpurun_out/pmc}
 export GS_VIEWS=${GS_VIEWS:-8}

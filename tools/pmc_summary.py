@@ -10,7 +10,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SIMDS, CUS, XCDS = 1024, 256, 8      # MI355X: 256 CUs x 4 SIMD-32, 8 XCDs (GRBM_GUI_ACTIVE is summed over them)
 
 SHORT = [("blend_bwd_quad", "blend_backward"), ("blend_fwd_quad", "blend_forward"), ("param_bwd", "param_backward"),
-         ("preprocess_batch_kernel", "preprocess"), ("preprocess_kernel", "preprocess"), ("image_loss_kernel", "image_loss"), ("radix_scatter", "radix_scatter"), ("radix_hist", "radix_hist"),
+         ("preprocess_batch_kernel", "preprocess"), ("preprocess_kernel", "preprocess"), ("image_loss_kernel", "image_loss"),
+         # the tile sort's kernels are told from the depth sort's by their template arguments: the tile sort moves
+         # (tile, gaussian) pairs (scatter MODE 1 / 2, histogram PAIRS = true or the tile-histogram kernel)
+         ("tile_hist_kernel", "tile_hist"), ("radix_hist_kernel<256, true>", "tile_hist2"), ("radix_hist_kernel<512, true>", "tile_hist2"),
+         ("radix_hist_kernel<256, (bool)1>", "tile_hist2"), ("radix_hist_kernel<512, (bool)1>", "tile_hist2"),
+         ("radix_hist", "depth_hist"), ("ranges_from_counts", "bin_ranges"),
          ("radix_scan", "radix_scan"), ("duplicate_kernel", "bin_duplicate"), ("pack_kernel", "blend_pack"),
          ("culled_pairs_kernel<false>", "bin_count_culled"), ("culled_pairs_kernel<true>", "bin_duplicate_culled"),
          ("culled_pairs_kernel<(bool)0>", "bin_count_culled"), ("culled_pairs_kernel<(bool)1>", "bin_duplicate_culled"),
@@ -19,6 +24,9 @@ SHORT = [("blend_bwd_quad", "blend_backward"), ("blend_fwd_quad", "blend_forward
 
 
 def short(name):
+    m = re.search(r"radix_scatter_kernel<(\d+), (\d+), (\d+)>", name)
+    if m:
+        return "depth_scatter" if m.group(3) == "0" else "tile_scatter"
     for pat, s in SHORT:
         if pat in name:
             return s
@@ -44,6 +52,7 @@ def main():
         durs = [sum(v) / len(v) for c, v in cs.items() if c.startswith("_dur_ns_")]
         e["avg_duration_us_under_pmc"] = sum(durs) / len(durs) / 1e3
         e["launches_per_pass"] = max(len(v) for c, v in cs.items() if not c.startswith("_"))
+        e["launches_per_view"] = e["launches_per_pass"] / float(os.environ.get("GS_VIEWS", 8))
         if "FETCH_SIZE" in e:
             e["fetch_bytes_raw"] = e["FETCH_SIZE"] * 1024
             e["fetch_bytes_corrected"] = 2 * e["FETCH_SIZE"] * 1024
@@ -72,8 +81,11 @@ def main():
         res[k] = e
     import bench
     res["_meta"] = {"source_sha16": bench.source_sha16(), "passes": dirs,
-                    "workload": "tools/one_view.py: bench scene (1M gaussians, 1920x1080, log-scale U(1,3)), GS_VIEWS views "
-                                "fwd+bwd on ONE stream, one batched K1 and K8"}
+                    "gaussians": int(os.environ.get("GS_N", 1_000_000)), "width": int(os.environ.get("GS_W", 1920)),
+                    "height": int(os.environ.get("GS_H", 1080)),
+                    "log_scale": [float(os.environ.get("GS_LS0", 1.0)), float(os.environ.get("GS_LS1", 3.0))],
+                    "lists": os.environ.get("GS_LISTS", "exact"), "views": int(os.environ.get("GS_VIEWS", 8)),
+                    "workload": "tools/one_view.py: bench scene, GS_VIEWS views fwd+bwd on ONE stream, one batched K1 and K8"}
     json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
     res.pop("_meta")
     for k, e in sorted(res.items(), key=lambda kv: -kv[1]["avg_duration_us_under_pmc"]):
