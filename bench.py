@@ -72,6 +72,7 @@ def parse():
                     help="local views in flight on separate streams (default: train_step's own rule, 4 lanes, or 2 "
                          "when a view carries >= 32 M (gaussian, tile) pairs)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: single-view forward render")
+    ap.add_argument("--fused-loss", action="store_true", help="train_step(fused_loss=True): loss gradient in K6's epilogue")
     ap.add_argument("--prepared-lists", action="store_true",
                     help="train_step(prepared=True): count / depth order / offsets per batch of views on the main stream")
     return ap.parse_args()
@@ -195,7 +196,7 @@ def main():
             image, _ = pipe.forward(views[0])
             return image
         return gs.train_step(pipe, views, targets, grads, concurrent_views=args.concurrent_views,
-                             k8_early_lanes=args.k8_early_lanes, prepared=args.prepared_lists)
+                             k8_early_lanes=args.k8_early_lanes, prepared=args.prepared_lists, fused_loss=args.fused_loss)
 
     trace = os.environ.get("GS_BENCH_TRACE") == "1"
 
@@ -369,7 +370,7 @@ def main():
         other_kind = "culled" if args.lists == "exact" else "exact"
         other_pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx, cull_tiles=other_kind == "culled")
         run = lambda: gs.train_step(other_pipe, views, targets, grads, concurrent_views=args.concurrent_views,
-                                    k8_early_lanes=args.k8_early_lanes, prepared=args.prepared_lists)
+                                    k8_early_lanes=args.k8_early_lanes, prepared=args.prepared_lists, fused_loss=args.fused_loss)
         for _ in range(3):
             run()
         torch.cuda.synchronize()

@@ -95,6 +95,8 @@ SIGNATURES = {
                                           _P, _P, _P]),
     "gs_blend_forward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),
                                         _I32, _I32, _I32, _F, _P, _P, _P]),
+    "gs_blend_forward_loss": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),
+                                             _I32, _I32, _I32, _F, _P, _P, _P, _P, _I32, _F, _P, _P]),
     "gs_blend_backward": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),
                                          _I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_blend_backward_noalloc": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(_F * 3),

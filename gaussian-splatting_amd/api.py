@@ -620,6 +620,27 @@ def blend_forward(c, centers, colors, opacities, conics, binning, bg, pixel_offs
     return image, n_contrib, t_final
 
 
+def blend_forward_loss(c, centers, colors, opacities, conics, binning, bg, pixel_offset, target, kind, scale, loss_out):
+    """gs_blend_forward_loss: K6 with the loss and dL/dimage in its epilogue.  loss_out (1-element device tensor) is
+    added to.  Returns (image, n_contrib, t_final, dL_dimage)."""
+    dev = c.device
+    W, H = binning.result_size
+    N = opacities.shape[0]
+    target = target.contiguous()
+    if tuple(target.shape) != (W, H, 3) or target.dtype != torch.float32:
+        raise ValueError("target must be a float32 tensor [W,H,3]")
+    image = torch.empty((W, H, 3), dtype=torch.float32, device=dev)
+    dL = torch.empty((W, H, 3), dtype=torch.float32, device=dev)
+    n_contrib = torch.empty((W, H), dtype=torch.int32, device=dev)
+    t_final = torch.empty((W, H), dtype=torch.float32, device=dev)
+    check(c.lib.gs_blend_forward_loss(c.handle, N, _ptr(centers), _ptr(colors), _ptr(opacities), _ptr(conics),
+                                      _ptr(binning.vals), _ptr(binning.ranges), binning.D, ctypes.byref(bg), W, H,
+                                      binning.tile_size, float(pixel_offset), _ptr(image), _ptr(n_contrib),
+                                      _ptr(t_final), _ptr(target), {"l1": 0, "l2": 1}[kind], float(scale), _ptr(dL),
+                                      _ptr(loss_out)), "gs_blend_forward_loss")
+    return image, n_contrib, t_final, dL
+
+
 def blend_backward(c, centers, colors, opacities, conics, binning, bg, pixel_offset, n_contrib, t_final,
                    dL_dimage):
     dev = c.device

@@ -358,6 +358,16 @@ struct QuadArgs {
     const int32_t *order;    // launch slot -> 16x16 block, heaviest first (NULL: spatial order)
 };
 
+// K6 with the loss in its epilogue (gs_blend_forward_loss): the pixel is still in registers when its target is
+// read, so the loss gradient costs no second pass over the image and no launch of its own
+struct LossArgs {
+    const float *target;     // [W,H,3]
+    float *dL;               // [W,H,3] out: d loss / d image
+    float *loss_out;         // += sum|diff| / n  (kind 0)  or  sum diff^2 / n  (kind 1), one float atomic per tile
+    float gscale, inv_n;     // scale / n, 1 / n   (n = W*H*3)
+    int kind;
+};
+
 // four threads per gaussian, one float4 of the record each: stores are fully coalesced
 __global__ __launch_bounds__(256) void pack_kernel(int N, const float2 *__restrict__ centers,
                                                    const float *__restrict__ colors,
@@ -429,9 +439,10 @@ __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballo
 #ifndef GS_FWD_WAVES
 #define GS_FWD_WAVES 7
 #endif
+template <bool LOSS>
 __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_kernel(QuadArgs a, float *__restrict__ image,
                                                                          int32_t *__restrict__ n_contrib,
-                                                                         float *__restrict__ t_final) {
+                                                                         float *__restrict__ t_final, LossArgs la) {
     // per wave: 64 staged records of 12 words (geo | con | rgb) at a fixed stride, so one address serves the
     // three reads of an entry; con.w = original list index + 1 (bits)
     __shared__ float4 s_rec_[QUAD_WAVES][3][64];
@@ -546,6 +557,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
         }
     }
 
+    float lsum = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int px = X0 + qx + 8 * (k >> 1), py = Y0 + qy + 8 * (k & 1);
@@ -553,12 +565,31 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
             const size_t pidx = (size_t)px * a.H + py;
             const bool broke = thr[k] == 0.0f;
             const float Tk = broke ? Tfin[k] : T[k];
-            image[3 * pidx] = __builtin_fmaf(a.bg[0], Tk, C[k][0]);
-            image[3 * pidx + 1] = __builtin_fmaf(a.bg[1], Tk, C[k][1]);
-            image[3 * pidx + 2] = __builtin_fmaf(a.bg[2], Tk, C[k][2]);
+            const float rgb[3] = {__builtin_fmaf(a.bg[0], Tk, C[k][0]), __builtin_fmaf(a.bg[1], Tk, C[k][1]),
+                                  __builtin_fmaf(a.bg[2], Tk, C[k][2])};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                image[3 * pidx + c] = rgb[c];
+                if (LOSS) {      // the arithmetic of image_loss_kernel (csrc/train.hip), per pixel
+                    const float d = rgb[c] - la.target[3 * pidx + c];
+                    if (la.kind == 0) {
+                        lsum += fabsf(d);
+                        la.dL[3 * pidx + c] = d > 0.0f ? la.gscale : (d < 0.0f ? -la.gscale : 0.0f);
+                    } else {
+                        lsum = __builtin_fmaf(d, d, lsum);
+                        la.dL[3 * pidx + c] = 2.0f * la.gscale * d;
+                    }
+                }
+            }
             n_contrib[pidx] = last[k] | (broke ? (int32_t)0x80000000 : 0);
             t_final[pidx] = Tk;
         }
+    }
+    if (LOSS) {
+        double s = (double)lsum;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) atomicAdd(la.loss_out, (float)(s * (double)la.inv_n));
     }
     GS_STAMP_END(0, len);
 }
@@ -1017,9 +1048,43 @@ extern "C" int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, co
             QuadArgs q;
             if ((rc = fill_quad(q, a, ctx, N))) return rc;
             gs_prof_scope prof_(ctx, GS_K_BLEND_FWD);
-            hipLaunchKernelGGL(blend_fwd_quad_kernel, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, image, n_contrib, t_final);
+            hipLaunchKernelGGL(blend_fwd_quad_kernel<false>, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream, q, image, n_contrib, t_final, LossArgs{});
         } break;
     }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// gs_blend_forward + gs_image_loss(accumulate = 1) in one launch: K6 forms the loss and dL/dimage in its epilogue.
+extern "C" int gs_blend_forward_loss(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                                     const float *opacities, const float *conics, const int32_t *vals,
+                                     const int32_t *ranges, int64_t D, const float *background_host3,
+                                     int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                                     float *image, int32_t *n_contrib, float *t_final, const float *target,
+                                     int32_t kind, float scale, float *dL_dimage, float *loss_out) {
+    GS_REQUIRE(kind == 0 || kind == 1, "gs_blend_forward_loss: kind %d (0 = L1, 1 = L2)", kind);
+    GS_REQUIRE(target && dL_dimage && loss_out, "gs_blend_forward_loss: NULL target / dL_dimage / loss_out");
+    const bool quad = ctx && (ctx->ext_records || ctx->ppt == 4);
+    if (!quad) {     // the 1- and 2-pixel kernels have no such epilogue: two calls
+        int rc = gs_blend_forward(ctx, N, centers, colors, opacities, conics, vals, ranges, D, background_host3, res_w,
+                                  res_h, tile_size, pixel_offset, image, n_contrib, t_final);
+        if (rc) return rc;
+        return gs_image_loss(ctx, (int64_t)res_w * res_h * 3, image, target, kind, scale, 1, dL_dimage, loss_out);
+    }
+    BlendArgs a;
+    int rc = fill_args(a, ctx, N, centers, colors, opacities, conics, vals, ranges, D, background_host3,
+                       res_w, res_h, tile_size, pixel_offset);
+    if (rc) return rc;
+    GS_REQUIRE(image && n_contrib && t_final, "gs_blend_forward_loss: NULL output");
+    GS_HIP(hipSetDevice(ctx->device));
+    const int tiles = gs_div_up(res_w, TILE) * a.tiles_y;
+    QuadArgs q;
+    if ((rc = fill_quad(q, a, ctx, N))) return rc;
+    const double n = (double)res_w * res_h * 3.0;
+    LossArgs la{target, dL_dimage, loss_out, (float)((double)scale / n), (float)(1.0 / n), kind};
+    gs_prof_scope prof_(ctx, GS_K_BLEND_FWD);
+    hipLaunchKernelGGL(blend_fwd_quad_kernel<true>, dim3(gs_div_up(tiles, QUAD_WAVES)), dim3(64 * QUAD_WAVES), 0, ctx->stream,
+                       q, image, n_contrib, t_final, la);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

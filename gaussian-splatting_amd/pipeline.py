@@ -190,8 +190,8 @@ class SplatPipeline:
             p["opac"] = opac
         return pres
 
-    def forward(self, view, want_keys=False, ctx=None, pre=None):
-        return self.forward_finish(self.forward_begin(view, ctx=ctx, pre=pre), want_keys=want_keys)
+    def forward(self, view, want_keys=False, ctx=None, pre=None, loss=None):
+        return self.forward_finish(self.forward_begin(view, ctx=ctx, pre=pre), want_keys=want_keys, loss=loss)
 
     def forward_begin(self, view, ctx=None, pre=None):
         """K1 (unless `pre` comes from preprocess_batch) and the launch of the tile count; the host
@@ -223,11 +223,11 @@ class SplatPipeline:
             tok["bin"] = api.bin_exact_begin(c, pre["rect"], pre["depths"], self.result_size, self.tile_size)
         return tok
 
-    def forward_finish(self, tok, want_keys=False, after_blend=None):
+    def forward_finish(self, tok, want_keys=False, after_blend=None, loss=None):
         """Waits for the tile count, then sort -> K6.  after_blend() (if given) runs right after K6 is
         enqueued: the lane scheduler uses it to launch the lane's NEXT count before this view's loss and K7."""
         self.forward_bin(tok, want_keys=want_keys)
-        out = self.forward_blend(tok)
+        out = self.forward_blend(tok, loss=loss)
         if after_blend is not None:
             after_blend()
         return out
@@ -243,18 +243,29 @@ class SplatPipeline:
             tok["binning"] = api.bin_culled_finish(tok["bin"], want_keys=want_keys)
         return tok["binning"]
 
-    def forward_blend(self, tok, ctx=None):
+    def forward_blend(self, tok, ctx=None, loss=None):
         """Third stage: K6 over the lists of forward_bin, on `ctx` (default: the ctx that binned the view; a
-        scheduler that bins on one stream and blends on another passes the blend lane's ctx)."""
+        scheduler that bins on one stream and blends on another passes the blend lane's ctx).
+        loss=(target[W,H,3], kind, scale, loss_out[1]): K6 also forms the loss and dL/dimage in its epilogue
+        (state["dL"]); loss_out is ADDED to (zero it first)."""
         pre, opac, binning = tok["pre"], tok["opac"], tok["binning"]
         c = ctx or tok["c"]
         c.sync_stream()
-        with _records(c, self.N, pre.get("rec")):
-            image, n_contrib, t_final = api.blend_forward(c, pre["centers"], pre["colors"], opac, pre["conics"],
-                                                          binning, self.bg, self.pixel_offset)
         state = dict(ctx=c, cam=pre["cam"], depths=pre["depths"], centers=pre["centers"], colors=pre["colors"],
                      conics=pre["conics"], clamped=pre["clamped"], radii=pre["radii"], opac=opac, binning=binning,
-                     n_contrib=n_contrib, t_final=t_final, rec=pre.get("rec"))
+                     rec=pre.get("rec"))
+        with _records(c, self.N, pre.get("rec")):
+            if loss is None:
+                image, n_contrib, t_final = api.blend_forward(c, pre["centers"], pre["colors"], opac, pre["conics"],
+                                                              binning, self.bg, self.pixel_offset)
+            else:
+                # K6 with the loss gradient in its epilogue (gs_blend_forward_loss): no separate pass over the image
+                target, kind, scale, loss_out = loss
+                image, n_contrib, t_final, dL = api.blend_forward_loss(c, pre["centers"], pre["colors"], opac,
+                                                                       pre["conics"], binning, self.bg,
+                                                                       self.pixel_offset, target, kind, scale, loss_out)
+                state["dL"] = dL
+        state["n_contrib"], state["t_final"] = n_contrib, t_final
         self.stats = dict(D=binning.D)
         return image, state
 
@@ -362,7 +373,15 @@ class Optimizer:
               "gs_adam_step")
 
 
-def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale):
+def _loss_and_rows(pipe, image, state, target, loss_kind, scale, loss_out):
+    """Loss gradient (unless K6 formed it: state["dL"]) and K7 of one rendered view, on the current stream."""
+    dL = state.pop("dL", None)
+    if dL is None:
+        dL, _ = pipe.image_loss(image, target, loss_kind, scale, loss_out, ctx=state["ctx"])
+    pipe.backward_rows(state, dL)
+
+
+def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale, fused_loss=False):
     """Forward, loss gradient and K7 of this rank's views on n_lanes concurrent lanes.  Returns
     (states, done events per view, lanes)."""
     main = pipe.ctx.current_stream()
@@ -407,19 +426,19 @@ def _render_on_lanes(pipe, views, mine, targets, losses, n_lanes, loss_kind, sca
         fwd = {}
         for k in ks:
             with pipe.ctx.use_stream(lanes[k % n_lanes][1]):
-                fwd[k] = pipe.forward_finish(tokens.pop(k), after_blend=lambda k=k: begin(k + n_lanes))
+                la = (targets[mine[k]], loss_kind, scale, losses[k:k + 1]) if fused_loss else None
+                fwd[k] = pipe.forward_finish(tokens.pop(k), after_blend=lambda k=k: begin(k + n_lanes), loss=la)
         for k in ks:
             stream = lanes[k % n_lanes][1]
             image, state = fwd[k]
             with pipe.ctx.use_stream(stream):
-                dL, _ = pipe.image_loss(image, targets[mine[k]], loss_kind, scale, losses[k:k + 1], ctx=state["ctx"])
-                pipe.backward_rows(state, dL)
+                _loss_and_rows(pipe, image, state, targets[mine[k]], loss_kind, scale, losses[k:k + 1])
                 done.append(stream.record_event())
             states.append(state)
     return states, done, lanes
 
 
-def _render_prepared(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale):
+def _render_prepared(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale, fused_loss=False):
     """The same work as _render_on_lanes with the front half of every view's lists -- count, depth order, scanned
     offsets -- done per BATCH of views on the main stream (gs_bin_prepare_begin / _end: a dozen launches and one host
     wait per batch instead of per view) and only what scales with the number of pairs -- emit, tile sort, ranges
@@ -479,14 +498,14 @@ def _render_prepared(pipe, views, mine, targets, losses, n_lanes, loss_kind, sca
                 stream.wait_event(ready[group_of[k]])
                 with _records(ctx, pipe.N, pres[k].get("rec")):
                     b = api.bin_fill_prepared(ctx, pres[k])
-                fwd[k] = pipe.forward_blend(dict(pre=pres[k], opac=pres[k]["opac"], binning=b, c=ctx))
+                la = (targets[mine[k]], loss_kind, scale, losses[k:k + 1]) if fused_loss else None
+                fwd[k] = pipe.forward_blend(dict(pre=pres[k], opac=pres[k]["opac"], binning=b, c=ctx), loss=la)
         ks = sorted(ks)
         for k in ks:
             stream = lanes[k % n_lanes][1]
             image, state = fwd[k]
             with pipe.ctx.use_stream(stream):
-                dL, _ = pipe.image_loss(image, targets[mine[k]], loss_kind, scale, losses[k:k + 1], ctx=state["ctx"])
-                pipe.backward_rows(state, dL)
+                _loss_and_rows(pipe, image, state, targets[mine[k]], loss_kind, scale, losses[k:k + 1])
                 done.append(stream.record_event())
             states.append(state)
     return states, done, lanes
@@ -566,7 +585,8 @@ def auto_lanes(pipe):
 
 
 def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2, loss_kind="l2", states_hook=None,
-               k8_early_lanes=None, allreduce_chunks=4, batch_binning=False, bin_group=4, prepared=False):
+               k8_early_lanes=None, allreduce_chunks=4, batch_binning=False, bin_group=4, prepared=False,
+               fused_loss=False):
     """Forward+backward over this rank's shard of `views`, then the all-reduce of the flat gradient
     buffer when torch.distributed is initialised.  targets[v] is the image [W,H,3] view v should
     match; the loss is the mean squared ("l2") or mean absolute ("l1") error summed over the views,
@@ -586,6 +606,10 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     (_render_prepared); False (default): every view builds its lists on its lane (_render_on_lanes).  Measured on
     MI355X at 1 M / 1080p / 8 views: 6.02-6.13 ms per step prepared (and 7.9 ms in some launch arrangements: the
     main stream then carries the batches' sorts AND a lane's blends) against 5.85-5.89 ms per view, so it is off.
+    fused_loss=True: K6 forms the loss and dL/dimage in its epilogue (gs_blend_forward_loss): one pass over the image
+    and two launches per view less; False (default): the separate gs_image_loss pass.  Measured on MI355X at 1 M /
+    1080p / 8 views: 5.91 ms fused against 5.82 ms -- the epilogue's 12-byte-per-lane target reads and dL stores are
+    worse streams than the loss kernel's float4s, and that outweighs the saved pass.
     Returns (sum of local losses as a device scalar, number of local views)."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -620,7 +644,7 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     elif n_lanes > 1:
         main = pipe.ctx.current_stream()
         render = _render_prepared if prepared else _render_on_lanes
-        states, done, lanes = render(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale)
+        states, done, lanes = render(pipe, views, mine, targets, losses, n_lanes, loss_kind, scale, fused_loss)
         # The lanes do not finish together (the hardware serves the queues in a fixed order): K8 of the
         # early lanes' views runs on lane 0's stream while the others still blend.
         if k8_early_lanes is None:
@@ -638,9 +662,9 @@ def train_step(pipe, views, targets, grads, loss_scale=None, concurrent_views=2,
     else:
         pres = pipe.preprocess_batch([views[v] for v in mine])
         for k, v in enumerate(mine):
-            image, state = pipe.forward(views[v], pre=pres[k])
-            dL, _ = pipe.image_loss(image, targets[v], loss_kind, scale, losses[k:k + 1])
-            pipe.backward_rows(state, dL)
+            la = (targets[v], loss_kind, scale, losses[k:k + 1]) if fused_loss else None
+            image, state = pipe.forward(views[v], pre=pres[k], loss=la)
+            _loss_and_rows(pipe, image, state, targets[v], loss_kind, scale, losses[k:k + 1])
             states.append(state)
     if states_hook is not None:      # e.g. Densifier.accumulate: per-view blend gradients are still alive here
         states_hook(states)

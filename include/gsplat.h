@@ -272,6 +272,20 @@ int gs_blend_forward(gs_ctx *ctx, int32_t N, const float *centers, const float *
                      int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
                      float *image, int32_t *n_contrib, float *t_final);
 
+/* gs_blend_forward with the training loss in the kernel's epilogue (no counterpart in the reference, whose loop
+ * forms an L1 figure on uint8 copies on the host, train.py:45-49, and no dL/dimage at all): every pixel is compared
+ * with target[W,H,3] while it is still in registers; dL_dimage[W,H,3] and the loss are those of gs_image_loss
+ * (kind 0: mean |image - target|, dL = scale * sign(diff) / n; kind 1: mean diff^2, dL = scale * 2 diff / n;
+ * n = W*H*3), except that loss_out[0] (device float) is ADDED to -- zero it first -- with one float atomic per
+ * 16x16 block, so its last bits depend on the arrival order.  One pass over the image and two launches per view
+ * less than gs_blend_forward + gs_image_loss. */
+int gs_blend_forward_loss(gs_ctx *ctx, int32_t N, const float *centers, const float *colors,
+                          const float *opacities, const float *conics, const int32_t *vals,
+                          const int32_t *ranges, int64_t D, const float *background_host3,
+                          int32_t res_w, int32_t res_h, int32_t tile_size, float pixel_offset,
+                          float *image, int32_t *n_contrib, float *t_final, const float *target,
+                          int32_t kind, float scale, float *dL_dimage, float *loss_out);
+
 /* Replaces the backward half of kernel rasterize (setup_gpu.py:105-165, intent; defects B4-B8
  * not reproduced): reverse-order traversal from each pixel's last contributor.
  * dL_dimage[W,H,3] is an explicit input (B4).  Outputs are zeroed by the call, then accumulated:

@@ -106,6 +106,11 @@ class FakeLib:
         l[0] = (l[0] if accumulate else 0.0) + float((d * d).mean())
         return 0
 
+    def gs_blend_forward_loss(self, h, n, cen, col, opa, con, vals, ranges, D, bg, w, hh, ts, off, image, nc, tf, target,
+                              kind, scale, dL, loss_out):
+        self.gs_blend_forward(h, n, cen, col, opa, con, vals, ranges, D, bg, w, hh, ts, off, image, nc, tf)
+        return self.gs_image_loss(h, w * hh * 3, image, target, kind, scale, 1, dL, loss_out)
+
     def gs_blend_backward_rows(self, h, n, cen, col, opa, con, vals, ranges, D, bg, w, hh, ts, off, nc, tf, dL, rows):
         v = self._view(h)
         r = _f32(rows, n * 16).reshape(n, 16)

@@ -214,3 +214,33 @@ def test_prepared_batch_lists_equal_the_per_view_calls(gpu_ctx, culled, W, H, ti
         assert Ds[k] == got.D == ref.D > 0
         assert torch.equal(got.ranges, ref.ranges) and torch.equal(got.vals, ref.vals) and torch.equal(got.keys, ref.keys)
     other.close()
+
+
+@pytest.mark.parametrize("kind", ["l1", "l2"])
+@pytest.mark.parametrize("W,H", [(320, 240), (203, 117)])
+def test_blend_forward_with_the_loss_in_its_epilogue(gpu_ctx, kind, W, H):
+    """gs_blend_forward_loss against gs_blend_forward followed by gs_image_loss: image, n_contrib, t_final and
+    dL/dimage bit for bit (the same arithmetic per pixel), the loss to float-atomics rounding, added to loss_out; and
+    train_step with and without the fused form gives the same gradients."""
+    import torch
+    import gsplat_amd as gs
+    cam, R, t, g, rs = synth_scene(8000, W, H, seed=9, fx=0.6 * W, log_scale=(1.5, 3.2))
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx, background=(.1, .2, .3))
+    view = gs.View(cam, R, t)
+    target = torch.rand(W, H, 3, generator=torch.Generator().manual_seed(3)).to(gpu_ctx.device)
+    img0, st0 = pipe.forward(view)
+    dL0, loss0 = pipe.image_loss(img0, target, kind, 0.7)
+    acc = torch.full((1,), 2.5, dtype=torch.float32, device=gpu_ctx.device)
+    img1, st1 = pipe.forward(view, loss=(target, kind, 0.7, acc))
+    torch.cuda.synchronize()
+    assert torch.equal(img0, img1) and torch.equal(st0["n_contrib"], st1["n_contrib"]) and torch.equal(st0["t_final"], st1["t_final"])
+    assert torch.equal(dL0, st1["dL"])
+    assert abs(float(acc) - 2.5 - float(loss0)) <= 2e-6 * max(float(loss0), 1.0) + 3e-7
+    views = [view, gs.View(cam, R, np.array([0.1, -0.05, 0.2])), gs.View(cam, R, np.array([-0.1, 0.05, 0.1]))]
+    targets = [target] * 3
+    ga, gb = gs.FlatGrads(pipe.N, gpu_ctx.device), gs.FlatGrads(pipe.N, gpu_ctx.device)
+    la, _ = gs.train_step(pipe, views, targets, ga, concurrent_views=2, loss_kind=kind, fused_loss=True)
+    lb, _ = gs.train_step(pipe, views, targets, gb, concurrent_views=2, loss_kind=kind, fused_loss=False)
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 3e-6 * float(lb)
+    assert float((ga.flat - gb.flat).abs().max()) <= 2e-5 * float(gb.flat.abs().max())

@@ -51,7 +51,7 @@ def main():
         e = {c: sum(v) / len(v) for c, v in cs.items() if not c.startswith("_dur_ns_")}
         durs = [sum(v) / len(v) for c, v in cs.items() if c.startswith("_dur_ns_")]
         e["avg_duration_us_under_pmc"] = sum(durs) / len(durs) / 1e3
-        e["launches_per_pass"] = max(len(v) for c, v in cs.items() if not c.startswith("_"))
+        e["launches_per_pass"] = min(len(v) for c, v in cs.items() if not c.startswith("_"))   # a counter of ONE pass
         e["launches_per_view"] = e["launches_per_pass"] / float(os.environ.get("GS_VIEWS", 8))
         if "FETCH_SIZE" in e:
             e["fetch_bytes_raw"] = e["FETCH_SIZE"] * 1024
