@@ -26,10 +26,41 @@ struct PreOut {
     double eW[6], eM[9], eT[3], eC2[3], eC3[6], eD[3];
 };
 
+// :74-76  the view-independent part of a gaussian: M = R(q) S and Sigma = M M^T.  Only scale_mod (3 / result height)
+// and the diag_scale switch come from the frame, and every view of a batch shares them, so the batched kernel
+// evaluates this ONCE per gaussian (three fp64 exps, a square root, four divisions and 54 multiply-adds less per
+// view); same operations in the same order as inside the per-view chain, so the outputs do not change by a bit.
+__device__ __forceinline__ void gaussian_cov(double sm, int diag_scale, double q0, double q1, double q2, double q3,
+                                             const float (&ls)[3], double (&M)[9], double (&Sg)[9]) {
+    // :74  rotation from the normalised quaternion (w,x,y,z); as_rotation_matrix divides by
+    // the squared norm once more
+    const double qn = sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
+    const double qw = q0 / qn, qx = q1 / qn, qy = q2 / qn, qz = q3 / qn;
+    const double s = 2.0 / (((qw * qw + qx * qx) + qy * qy) + qz * qz);
+    const double R[9] = {1 - s * (qy * qy + qz * qz), s * (qx * qy - qz * qw), s * (qx * qz + qy * qw),
+                         s * (qx * qy + qz * qw), 1 - s * (qx * qx + qz * qz), s * (qy * qz - qx * qw),
+                         s * (qx * qz - qy * qw), s * (qy * qz + qx * qw), 1 - s * (qx * qx + qy * qy)};
+    // :75  M = R @ ([[s0,1,1],[1,s1,1],[1,1,s2]] * scale_mod) (quirk Q4)
+    const double so = diag_scale ? 0.0 : sm;       // off-diagonals: 1 * scale_mod in the reference
+    const double S[9] = {exp((double)ls[0]) * sm, so, so,
+                         so, exp((double)ls[1]) * sm, so,
+                         so, so, exp((double)ls[2]) * sm};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            M[3 * r + c] = (R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c]) + R[3 * r + 2] * S[6 + c];
+    // :76  Sigma = M M^T
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            Sg[3 * r + c] = (M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1]) + M[3 * r + 2] * M[3 * c + 2];
+}
+
 template <bool EXTRAS>
-__device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, double y, double z, double q0, double q1,
-                                               double q2, double q3, const float (&ls)[3], const float (&coef)[48],
-                                               PreOut &o) {
+__device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, double y, double z, const double (&M)[9],
+                                               const double (&Sg)[9], const float (&coef)[48], PreOut &o) {
     // outputs of a culled gaussian are all zero (the reference pre-zeroes, forward_pass.py:29-41)
     o.cx = o.cy = 0.f;
     for (int k = 0; k < 3; k++) { o.col[k] = 0.f; o.con[k] = 0.f; o.cl[k] = 0; }
@@ -67,35 +98,6 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
                 o.depth = (int)((w < 0 ? w + 4294967296.0 : w) - 2147483648.0);
             }
         }
-
-        // :74  rotation from the normalised quaternion (w,x,y,z); as_rotation_matrix divides by
-        // the squared norm once more
-        const double qn = sqrt(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
-        const double qw = q0 / qn, qx = q1 / qn, qy = q2 / qn, qz = q3 / qn;
-        const double s = 2.0 / (((qw * qw + qx * qx) + qy * qy) + qz * qz);
-        const double R[9] = {1 - s * (qy * qy + qz * qz), s * (qx * qy - qz * qw), s * (qx * qz + qy * qw),
-                             s * (qx * qy + qz * qw), 1 - s * (qx * qx + qz * qz), s * (qy * qz - qx * qw),
-                             s * (qx * qz - qy * qw), s * (qy * qz + qx * qw), 1 - s * (qx * qx + qy * qy)};
-
-        // :75  M = R @ ([[s0,1,1],[1,s1,1],[1,1,s2]] * scale_mod) (quirk Q4)
-        const double sm = cam.scale_mod;
-        const double so = cam.diag_scale ? 0.0 : sm;       // off-diagonals: 1 * scale_mod in the reference
-        const double S[9] = {exp((double)ls[0]) * sm, so, so,
-                             so, exp((double)ls[1]) * sm, so,
-                             so, so, exp((double)ls[2]) * sm};
-        double M[9];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                M[3 * r + c] = (R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c]) + R[3 * r + 2] * S[6 + c];
-        // :76  Sigma = M M^T
-        double Sg[9];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                Sg[3 * r + c] = (M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1]) + M[3 * r + 2] * M[3 * c + 2];
 
         // :78-82  W = J^T @ camera_r^T; only rows 0,1 reach cov_2d[0:2,0:2] (quirk Q5)
         const double j00 = cam.fx / tz, j11 = cam.fy / tz;
@@ -237,7 +239,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float ls[3], coef[48];
     load_params(i, means, log_scales, quats, sh, x, y, z, q, ls, coef);
     PreOut o;
-    preprocess_one<true>(cam, x, y, z, q[0], q[1], q[2], q[3], ls, coef, o);
+    double M[9], Sg[9];
+    gaussian_cov(cam.scale_mod, cam.diag_scale, q[0], q[1], q[2], q[3], ls, M, Sg);
+    preprocess_one<true>(cam, x, y, z, M, Sg, coef, o);
     store_view(i, out, o);
     if (Ws) for (int k = 0; k < 6; k++) Ws[6 * i + k] = (float)o.eW[k];
     if (Ms) for (int k = 0; k < 9; k++) Ms[9 * i + k] = (float)o.eM[k];
@@ -271,11 +275,16 @@ __global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const floa
     float ls[3], coef[48];
     load_params(i, means, log_scales, quats, sh, x, y, z, q, ls, coef);
     const float opac = RECORDS ? opacities[i] : 0.0f;
+    // M and Sigma once per gaussian: the host has checked that the views share scale_mod and the scale switch
+    double M[9], Sg[9];
+    gaussian_cov(b.cam[0].scale_mod, b.cam[0].diag_scale, q[0], q[1], q[2], q[3], ls, M, Sg);
 #pragma unroll 1
     for (int v = 0; v < b.n_views; v++) {
         PreOut o;
-        preprocess_one<false>(b.cam[v], x, y, z, q[0], q[1], q[2], q[3], ls, coef, o);
+        preprocess_one<false>(b.cam[v], x, y, z, M, Sg, coef, o);
         if (RECORDS) {
+            // (staging the block's records through LDS so that a wave stores 1 KiB pieces was measured: 0.269 against
+            // 0.251 ms per 8 views -- a thread's four consecutive float4 stores are combined well enough as they are)
             const ViewOut &w = b.out[v];
             w.depths[i] = o.depth;
             w.radii[i] = o.rad;
@@ -368,14 +377,20 @@ extern "C" int gs_preprocess_batch(gs_ctx *ctx, int32_t N, const float *means, c
         GS_REQUIRE(((uintptr_t)w.tiles_touched & 15) == 0, "gs_preprocess_batch: tiles_touched must be 16-byte aligned");
     }
     GS_HIP(hipSetDevice(ctx->device));
-    for (int done = 0; done < n_views; done += MAX_PRE_VIEWS) {
+    for (int done = 0; done < n_views; done += 0) {
         PreBatch b;
-        b.n_views = n_views - done < MAX_PRE_VIEWS ? n_views - done : MAX_PRE_VIEWS;
-        for (int v = 0; v < b.n_views; v++) {
+        b.n_views = 0;
+        // a launch takes up to 8 consecutive views that share what Sigma depends on (the result height's scale_mod
+        // and the scale switch): the kernel forms M and Sigma once per gaussian for all of them
+        while (done + b.n_views < n_views && b.n_views < MAX_PRE_VIEWS) {
+            const int v = b.n_views;
             const gs_view_preprocess &w = views[done + v];
             gs_make_precam(w.cam, &b.cam[v]);
+            if (v > 0 && (b.cam[v].scale_mod != b.cam[0].scale_mod || b.cam[v].diag_scale != b.cam[0].diag_scale)) break;
             b.out[v] = ViewOut{w.centers, w.colors, w.conics, w.depths, w.tiles_touched, w.radii, w.clamped, nullptr};
+            b.n_views++;
         }
+        done += b.n_views;
         { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_batch_kernel<false>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                            means, log_scales, quats, sh, (const float *)nullptr, b); }
         GS_HIP(hipGetLastError());
@@ -406,15 +421,19 @@ extern "C" int gs_preprocess_batch_records(gs_ctx *ctx, int32_t N, const float *
                    "gs_preprocess_batch_records: tiles_touched and records must be 16-byte aligned");
     }
     GS_HIP(hipSetDevice(ctx->device));
-    for (int done = 0; done < n_views; done += MAX_PRE_VIEWS) {
+    for (int done = 0; done < n_views; done += 0) {
         PreBatch b;
-        b.n_views = n_views - done < MAX_PRE_VIEWS ? n_views - done : MAX_PRE_VIEWS;
-        for (int v = 0; v < b.n_views; v++) {
+        b.n_views = 0;
+        while (done + b.n_views < n_views && b.n_views < MAX_PRE_VIEWS) {      // as in gs_preprocess_batch
+            const int v = b.n_views;
             const gs_view_records &w = views[done + v];
             gs_make_precam(w.cam, &b.cam[v]);
+            if (v > 0 && (b.cam[v].scale_mod != b.cam[0].scale_mod || b.cam[v].diag_scale != b.cam[0].diag_scale)) break;
             b.out[v] = ViewOut{nullptr, nullptr, nullptr, w.depths, w.tiles_touched, w.radii, w.clamped,
                                reinterpret_cast<float4 *>(w.records)};
+            b.n_views++;
         }
+        done += b.n_views;
         { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_batch_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                            means, log_scales, quats, sh, opacities, b); }
         GS_HIP(hipGetLastError());
