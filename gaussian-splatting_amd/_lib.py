@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+# GSPLAT_LIB: another build of the same library (tools/variant_bench.py builds A/B variants with extra -D flags)
+LIB_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(_HERE, "libgsplat_hip.so")
 
 
 class GsCamera(ctypes.Structure):

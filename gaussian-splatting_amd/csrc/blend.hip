@@ -447,6 +447,10 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_FWD_WAVES) void blend_fwd_quad_
     // three reads of an entry; con.w = original list index + 1 (bits)
     __shared__ float4 s_rec_[QUAD_WAVES][3][64];
     __shared__ unsigned s_qm_[QUAD_WAVES][64];
+#ifdef GS_FWD_LDS_PAD      // experiment: caps the workgroups per CU (wave slots left to other kernels), see DESIGN.md
+    __shared__ unsigned s_pad_[GS_FWD_LDS_PAD / 4];
+    if (a.W < 0) s_pad_[threadIdx.x] = 0u;
+#endif
 
     const int wv = threadIdx.x >> 6;
     const int slot = blockIdx.x * QUAD_WAVES + wv;
@@ -620,6 +624,10 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     // rgb.x; rgb.w keeps the gaussian id for the flush.
     __shared__ float4 s_rec_[QUAD_WAVES][3][64];
     __shared__ unsigned s_qm_[QUAD_WAVES][64];
+#ifdef GS_BWD_LDS_PAD      // experiment: caps the workgroups per CU (wave slots left to other kernels), see DESIGN.md
+    __shared__ unsigned s_pad_[GS_BWD_LDS_PAD / 4];
+    if (a.W < 0) s_pad_[threadIdx.x] = 0u;
+#endif
 
     const int wv = threadIdx.x >> 6;
     const int slot = blockIdx.x * QUAD_WAVES + wv;

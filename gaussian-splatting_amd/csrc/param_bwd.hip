@@ -19,6 +19,7 @@
 #include "common.h"
 #include "precam.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -43,7 +44,10 @@ struct BatchArgs {
 #ifndef GS_K8_WAVES
 #define GS_K8_WAVES 2
 #endif
-template <bool ROWS>
+// FAST (chosen per launch on the host): every view has SH degree 3 and the strict clip-space centre, so the degree
+// tests of the 48-term sums fold away (a select per term otherwise); same formulas, results equal to fp32 rounding
+// (FMA contraction is on in this file and differs between the two forms).
+template <bool ROWS, bool FAST>
 __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
     int N, const float *__restrict__ means, const float *__restrict__ log_scales,
     const float *__restrict__ quats, const float *__restrict__ sh, const float *__restrict__ opacity,
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
     for (int v = 0; v < args.n_views; v++) {
         const PreCam &cam = args.v[v].cam;
         const Inputs in = nxt;
+        const int degree = FAST ? 3 : cam.degree;
         if (v + 1 < args.n_views) nxt = fetch(v + 1);
         if (in.radius <= 0) continue;
         any = true;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
         const double tz = cam.Rt[6] * x + cam.Rt[7] * y + cam.Rt[8] * z + cam.t[2];
 
         // ---- 2D centre <- world mean (quirk Q1: proj_mat on world coordinates)
-        if (!cam.apply_view) {
+        if (FAST || !cam.apply_view) {
             const double dcx = in_c[0], dcy = in_c[1];
             const double mw = 1.0 / (z + .00000001);
             g_mean[0] += dcx * (.5 * cam.W * cam.p00 * mw);
@@ -155,7 +160,8 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
             for (int k = 0; k < 3; k++) g_mean[k] += d_tx * cam.Rt[k] + d_ty * cam.Rt[3 + k] + d_tzc * cam.Rt[6 + k];
         }
 
-        const double j00 = cam.fx / tz, j11 = cam.fy / tz;
+        const double tz_inv = 1.0 / tz;
+        const double j00 = cam.fx * tz_inv, j11 = cam.fy * tz_inv;
         const double W0[3] = {j00 * cam.Rt[0], j00 * cam.Rt[1], j00 * cam.Rt[2]};
         const double W1[3] = {j11 * cam.Rt[3], j11 * cam.Rt[4], j11 * cam.Rt[5]};
         double u0[3], u1[3];
@@ -178,26 +184,31 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
 
         // ---- cov2d -> tz (through the 1/tz of both W rows) -> mean
         {
-            const double d_tz = -2.0 * (d_a * a0 + d_b * b + d_c * c0) / tz;
+            const double d_tz = -2.0 * (d_a * a0 + d_b * b + d_c * c0) * tz_inv;
             g_mean[0] += d_tz * cam.Rt[6];
             g_mean[1] += d_tz * cam.Rt[7];
             g_mean[2] += d_tz * cam.Rt[8];
         }
 
         // ---- cov2d -> Sigma: G + G^T, summed over the views (Sigma does not depend on the view)
-        for (int r = 0; r < 3; r++)
-            for (int cc = 0; cc < 3; cc++) {
-                const double g_rc = d_a * W0[r] * W0[cc] + d_b * W0[r] * W1[cc] + d_c * W1[r] * W1[cc];
-                const double g_cr = d_a * W0[cc] * W0[r] + d_b * W0[cc] * W1[r] + d_c * W1[cc] * W1[r];
-                H[3 * r + cc] += g_rc + g_cr;
+        // (H is symmetric: six entries, H_rc = 2 d_a W0r W0c + d_b (W0r W1c + W1r W0c) + 2 d_c W1r W1c)
+        {
+            double aW0[3], bW0[3], bW1[3], cW1[3];
+            for (int r = 0; r < 3; r++) {
+                aW0[r] = 2.0 * d_a * W0[r]; cW1[r] = 2.0 * d_c * W1[r];
+                bW0[r] = d_b * W0[r]; bW1[r] = d_b * W1[r];
             }
+            for (int r = 0; r < 3; r++)
+                for (int cc = r; cc < 3; cc++)
+                    H[3 * r + cc] += aW0[r] * W0[cc] + bW0[r] * W1[cc] + bW1[r] * W0[cc] + cW1[r] * W1[cc];
+        }
         // ---- colour -> SH coefficients and view direction -> mean (py_compute_color).  The direction
         // is normalised in fp64; the SH polynomial, its gradient and the 48-term sums are fp32 (an
         // outer product and short dot products: 1e-6 relative is far inside the 1e-4 bar, at half
         // the registers and issue cycles of fp64).
         double vx = x - cam.cam_pos[0], vy = y - cam.cam_pos[1], vz = z - cam.cam_pos[2];
-        const double vn = sqrt(vx * vx + vy * vy + vz * vz);
-        const double ddx_n = vx / vn, ddy_n = vy / vn, ddz_n = vz / vn;
+        const double vn_inv = 1.0 / sqrt(vx * vx + vy * vy + vz * vz);
+        const double ddx_n = vx * vn_inv, ddy_n = vy * vn_inv, ddz_n = vz * vn_inv;
         const float dx = (float)ddx_n, dy = (float)ddy_n, dz = (float)ddz_n;
         float basis[16], bx[16], by[16], bz[16];
 #pragma unroll
@@ -208,11 +219,11 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
         constexpr float C30 = (float)SH_C3_0, C31 = (float)SH_C3_1, C32 = (float)SH_C3_2, C33 = (float)SH_C3_3,
                         C34 = (float)SH_C3_4, C35 = (float)SH_C3_5, C36 = (float)SH_C3_6;
         basis[0] = C0;
-        if (cam.degree > 0) {
+        if (degree > 0) {
             basis[1] = -dy * C1; by[1] = -C1;
             basis[2] = dz * C1;  bz[2] = C1;
             basis[3] = -dx * C1; bx[3] = -C1;
-            if (cam.degree > 1) {
+            if (degree > 1) {
                 const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
                 basis[4] = C20 * xy; bx[4] = C20 * dy; by[4] = C20 * dx;
                 basis[5] = C21 * yz; by[5] = C21 * dz; bz[5] = C21 * dy;
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
                 bx[6] = -2.0f * C22 * dx; by[6] = -2.0f * C22 * dy; bz[6] = 4.0f * C22 * dz;
                 basis[7] = C23 * xz; bx[7] = C23 * dz; bz[7] = C23 * dx;
                 basis[8] = C24 * (xx - yy); bx[8] = 2.0f * C24 * dx; by[8] = -2.0f * C24 * dy;
-                if (cam.degree > 2) {
+                if (degree > 2) {
                     basis[9] = C30 * dy * (3.0f * xx - yy);
                     bx[9] = C30 * 6.0f * xy; by[9] = C30 * (3.0f * xx - 3.0f * yy);
                     basis[10] = C31 * xy * dz;
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
                 }
             }
         }
-        const int nb = (cam.degree + 1) * (cam.degree + 1);
+        const int nb = (degree + 1) * (degree + 1);
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // dL/d(dir)
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -265,13 +276,14 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
         }
         // dir = v/|v|: dL/dv = (dL/ddir - dir (dir . dL/ddir)) / |v|   (dnormvdv, setup_gpu.py:256-266)
         const double dot = ddx_n * ddx + ddy_n * ddy + ddz_n * ddz;
-        g_mean[0] += ((double)ddx - ddx_n * dot) / vn;
-        g_mean[1] += ((double)ddy - ddy_n * dot) / vn;
-        g_mean[2] += ((double)ddz - ddz_n * dot) / vn;
+        g_mean[0] += ((double)ddx - ddx_n * dot) * vn_inv;
+        g_mean[1] += ((double)ddy - ddy_n * dot) * vn_inv;
+        g_mean[2] += ((double)ddz - ddz_n * dot) * vn_inv;
     }
 
     if (any) {
         // ---- Sigma -> M: dM = (G + G^T) M
+        H[3] = H[1]; H[6] = H[2]; H[7] = H[5];      // the loop keeps the upper triangle
         double dM[9];
         for (int r = 0; r < 3; r++)
             for (int cc = 0; cc < 3; cc++)
@@ -331,6 +343,13 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
     }
 }
 
+bool bwd_fast(const BatchArgs &a) {
+    if (getenv("GS_K8_GENERAL")) return false;      // tests compare the two forms
+    for (int v = 0; v < a.n_views; v++)
+        if (a.v[v].cam.degree != 3 || a.v[v].cam.apply_view) return false;
+    return true;
+}
+
 int check_common(gs_ctx *ctx, int32_t N, const gs_camera *cam) {
     GS_REQUIRE(ctx && cam, "gs_backward_params: ctx/cam is NULL");
     GS_REQUIRE(N >= 0, "gs_backward_params: N=%d < 0", N);
@@ -363,7 +382,9 @@ extern "C" int gs_backward_params(gs_ctx *ctx, int32_t N, const float *means, co
     args.v[0].radii = radii; args.v[0].clamped = clamped;
     args.v[0].d_centers = dL_dcenters; args.v[0].d_conics = dL_dconics; args.v[0].d_colors = dL_dcolors;
     GS_HIP(hipSetDevice(ctx->device));
-    { gs_prof_scope prof_(ctx, GS_K_PARAM_BWD); hipLaunchKernelGGL(param_bwd_kernel<false>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
+    { gs_prof_scope prof_(ctx, GS_K_PARAM_BWD);
+      auto kern = bwd_fast(args) ? param_bwd_kernel<false, true> : param_bwd_kernel<false, false>;
+      hipLaunchKernelGGL(kern, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
                        log_scales, quats, sh, (const float *)nullptr, 0, args, accumulate, dL_dmeans, dL_dlog_scales,
                        dL_dquats, (float *)nullptr, dL_dsh); }
     GS_HIP(hipGetLastError());
@@ -406,7 +427,9 @@ extern "C" int gs_backward_params_batch(gs_ctx *ctx, int32_t N, const float *mea
             gs_make_precam(src.cam, &args.v[v].cam);
             args.v[v].radii = src.radii; args.v[v].clamped = src.clamped; args.v[v].rows = src.grad_rows;
         }
-        { gs_prof_scope prof_(ctx, GS_K_PARAM_BWD); hipLaunchKernelGGL(param_bwd_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
+        { gs_prof_scope prof_(ctx, GS_K_PARAM_BWD);
+          auto kern = bwd_fast(args) ? param_bwd_kernel<true, true> : param_bwd_kernel<true, false>;
+          hipLaunchKernelGGL(kern, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means,
                            log_scales, quats, sh, opacity, opacity_is_logit, args, (accumulate || done > 0) ? 1 : 0,
                            dL_dmeans, dL_dlog_scales, dL_dquats, dL_dopacity, dL_dsh); }
         GS_HIP(hipGetLastError());

@@ -12,6 +12,8 @@ struct PreCam {
     double scale_mod;      // 3 / result_size[1]    (forward_pass.py:50)
     int W, H, tile, degree;
     int apply_view, diag_scale;   // gs_camera.flags (0, 0 = strict reference)
+    double inv_tile;       // 1 / tile; v * inv_tile == v / tile bit for bit when tile is a power of two (tile_pow2)
+    int tile_pow2;
 };
 
 // forward_pass.py:8-21

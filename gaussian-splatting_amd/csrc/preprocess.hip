@@ -8,14 +8,17 @@
 #include "common.h"
 #include "precam.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
 // int(min(size, max(0, v)) / tile) with Python's min/max semantics (forward_pass.py:116-119)
-__device__ inline int clamp_to_tile(double v, double size, double tile) {
+// FAST: the tile size is a power of two, so the division is the multiplication by its (exact) reciprocal
+template <bool FAST>
+__device__ inline int clamp_to_tile(double v, double size, double tile, double inv_tile) {
     double m = (v > 0.0) ? v : 0.0;
     m = (m < size) ? m : size;
-    return (int)(m / tile);
+    return (int)(FAST ? m * inv_tile : m / tile);
 }
 
 // everything of one gaussian that depends on the view; `coef` holds its 48 SH coefficients
@@ -58,7 +61,11 @@ __device__ __forceinline__ void gaussian_cov(double sm, int diag_scale, double q
             Sg[3 * r + c] = (M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1]) + M[3 * r + 2] * M[3 * c + 2];
 }
 
-template <bool EXTRAS>
+// FAST (chosen per launch on the host, pre_fast()): SH degree 3, clip-space centre from world coordinates (the strict
+// reference) and a power-of-two tile size for every view of the launch -- the degree and flag tests below fold away
+// (they cost two selects per fp64 term of the colour sums otherwise) and the four tile divisions become exact
+// multiplications.  Same operations on the same values: outputs identical to the general form bit for bit.
+template <bool EXTRAS, bool FAST>
 __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, double y, double z, const double (&M)[9],
                                                const double (&Sg)[9], const float (&coef)[48], PreOut &o) {
     // outputs of a culled gaussian are all zero (the reference pre-zeroes, forward_pass.py:29-41)
@@ -80,7 +87,9 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
 
         // :59-61  clip-space centre from WORLD coordinates (quirk Q1); GS_CAM_APPLY_VIEW: from the view-space
         // position (the line the reference has commented out, :57)
-        const double hx = cam.apply_view ? tx : x, hy = cam.apply_view ? ty : y, hz = cam.apply_view ? tz : z;
+        const bool view_space = !FAST && cam.apply_view;
+        const int degree = FAST ? 3 : cam.degree;
+        const double hx = view_space ? tx : x, hy = view_space ? ty : y, hz = view_space ? tz : z;
         const double mod_w = 1.0 / (hz + .00000001);
         const double ndc_x = (cam.p00 * hx) * mod_w;
         const double ndc_y = (cam.p11 * hy) * mod_w;
@@ -100,7 +109,9 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
         }
 
         // :78-82  W = J^T @ camera_r^T; only rows 0,1 reach cov_2d[0:2,0:2] (quirk Q5)
-        const double j00 = cam.fx / tz, j11 = cam.fy / tz;
+        const double j00 = cam.fx / tz;
+        double j11 = j00;                               // square pixels: the same quotient
+        if (cam.fy != cam.fx) j11 = cam.fy / tz;
         const double W0[3] = {j00 * cam.Rt[0], j00 * cam.Rt[1], j00 * cam.Rt[2]};
         const double W1[3] = {j11 * cam.Rt[3], j11 * cam.Rt[4], j11 * cam.Rt[5]};
         double u0[3], u1[3];   // Sigma @ W0, Sigma @ W1
@@ -143,10 +154,10 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
         // the off-screen cull (quirk Q10)
         const double cx = ((ndc_x + 1.0) * cam.W - 1.0) * .5;
         const double cy = ((ndc_y + 1.0) * cam.H - 1.0) * .5;
-        o.rect[0] = clamp_to_tile(cx - radius, cam.W, cam.tile);
-        o.rect[1] = clamp_to_tile(cy - radius, cam.H, cam.tile);
-        o.rect[2] = clamp_to_tile(cx + radius + cam.tile - 1, cam.W, cam.tile);
-        o.rect[3] = clamp_to_tile(cy + radius + cam.tile - 1, cam.H, cam.tile);
+        o.rect[0] = clamp_to_tile<FAST>(cx - radius, cam.W, cam.tile, cam.inv_tile);
+        o.rect[1] = clamp_to_tile<FAST>(cy - radius, cam.H, cam.tile, cam.inv_tile);
+        o.rect[2] = clamp_to_tile<FAST>(cx + radius + cam.tile - 1, cam.W, cam.tile, cam.inv_tile);
+        o.rect[3] = clamp_to_tile<FAST>(cy + radius + cam.tile - 1, cam.H, cam.tile, cam.inv_tile);
 
         // :122-123  off-screen cull
         if (cx + radius < 0 || cx - radius > cam.W || cy + radius < 0 || cy - radius > cam.H) break;
@@ -157,19 +168,21 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
 
         // :127 -> py_compute_color (:168-215)
         double dx = x - cam.cam_pos[0], dy = y - cam.cam_pos[1], dz = z - cam.cam_pos[2];
-        const double dn = sqrt((dx * dx + dy * dy) + dz * dz);
-        dx /= dn; dy /= dn; dz /= dn;
+        // The colour is a float output (tolerance, not bits; the reference's own sums associate differently, :178-203):
+        // one division and three products for the direction, fused multiply-adds for the 48-term sums.
+        const double dn_inv = 1.0 / sqrt((dx * dx + dy * dy) + dz * dz);
+        dx *= dn_inv; dy *= dn_inv; dz *= dn_inv;
         if (EXTRAS) { o.eD[0] = dx; o.eD[1] = dy; o.eD[2] = dz; }
         double basis[16];
         basis[0] = SH_C0;
-        if (cam.degree > 0) {
+        if (degree > 0) {
             basis[1] = -dy * SH_C1; basis[2] = dz * SH_C1; basis[3] = -dx * SH_C1;
-            if (cam.degree > 1) {
+            if (degree > 1) {
                 const double xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
                 basis[4] = SH_C2_0 * xy; basis[5] = SH_C2_1 * yz;
                 basis[6] = SH_C2_2 * (2.0 * zz - xx - yy);
                 basis[7] = SH_C2_3 * xz; basis[8] = SH_C2_4 * (xx - yy);
-                if (cam.degree > 2) {
+                if (degree > 2) {
                     basis[9] = SH_C3_0 * dy * (3.0 * xx - yy);
                     basis[10] = SH_C3_1 * xy * dz;
                     basis[11] = SH_C3_2 * dy * (4.0 * zz - xx - yy);
@@ -180,13 +193,13 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
                 }
             }
         }
-        const int nb = (cam.degree + 1) * (cam.degree + 1);
+        const int nb = (degree + 1) * (degree + 1);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             double r = 0.0;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (k < nb) r += basis[k] * (double)coef[16 * ch + k];
+                if (k < nb) r = __builtin_fma(basis[k], (double)coef[16 * ch + k], r);
             r += .5;
             if (r < 0) { r = 0; o.cl[ch] = 1; }
             o.col[ch] = (float)r;
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     PreOut o;
     double M[9], Sg[9];
     gaussian_cov(cam.scale_mod, cam.diag_scale, q[0], q[1], q[2], q[3], ls, M, Sg);
-    preprocess_one<true>(cam, x, y, z, M, Sg, coef, o);
+    preprocess_one<true, false>(cam, x, y, z, M, Sg, coef, o);
     store_view(i, out, o);
     if (Ws) for (int k = 0; k < 6; k++) Ws[6 * i + k] = (float)o.eW[k];
     if (Ms) for (int k = 0; k < 9; k++) Ms[9 * i + k] = (float)o.eM[k];
@@ -263,7 +276,7 @@ struct PreBatch {
 
 // RECORDS: instead of centers / colors / conics each view gets the 64-byte blend records (common.h) the
 // blend and culled-binning kernels read, built from the activated opacities: no pack pass per view.
-template <bool RECORDS>
+template <bool RECORDS, bool FAST>
 __global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const float *__restrict__ means,
                                                                const float *__restrict__ log_scales,
                                                                const float *__restrict__ quats,
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const floa
 #pragma unroll 1
     for (int v = 0; v < b.n_views; v++) {
         PreOut o;
-        preprocess_one<false>(b.cam[v], x, y, z, M, Sg, coef, o);
+        preprocess_one<false, FAST>(b.cam[v], x, y, z, M, Sg, coef, o);
         if (RECORDS) {
             // (staging the block's records through LDS so that a wave stores 1 KiB pieces was measured: 0.269 against
             // 0.251 ms per 8 views -- a thread's four consecutive float4 stores are combined well enough as they are)
@@ -299,6 +312,14 @@ __global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const floa
             store_view(i, b.out[v], o);
         }
     }
+}
+
+// every view of the launch qualifies for the FAST form of preprocess_one
+bool pre_fast(const PreBatch &b) {
+    if (getenv("GS_K1_GENERAL")) return false;      // tests compare the two forms
+    for (int v = 0; v < b.n_views; v++)
+        if (b.cam[v].degree != 3 || b.cam[v].apply_view || !b.cam[v].tile_pow2) return false;
+    return true;
 }
 
 }  // namespace
@@ -323,6 +344,8 @@ int gs_make_precam(const gs_camera *cam, PreCam *out) {
     pc.W = cam->res_w; pc.H = cam->res_h; pc.tile = cam->tile_size; pc.degree = cam->sh_degree;
     pc.apply_view = (cam->flags & GS_CAM_APPLY_VIEW) ? 1 : 0;
     pc.diag_scale = (cam->flags & GS_CAM_DIAG_SCALE) ? 1 : 0;
+    pc.inv_tile = 1.0 / pc.tile;
+    pc.tile_pow2 = (pc.tile & (pc.tile - 1)) == 0;
     return GS_OK;
 }
 
@@ -391,8 +414,10 @@ extern "C" int gs_preprocess_batch(gs_ctx *ctx, int32_t N, const float *means, c
             b.n_views++;
         }
         done += b.n_views;
-        { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_batch_kernel<false>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
-                           means, log_scales, quats, sh, (const float *)nullptr, b); }
+        { gs_prof_scope prof_(ctx, GS_K_PREPROCESS);
+          auto kern = pre_fast(b) ? preprocess_batch_kernel<false, true> : preprocess_batch_kernel<false, false>;
+          hipLaunchKernelGGL(kern, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means, log_scales, quats, sh,
+                             (const float *)nullptr, b); }
         GS_HIP(hipGetLastError());
     }
     return GS_OK;
@@ -434,8 +459,10 @@ extern "C" int gs_preprocess_batch_records(gs_ctx *ctx, int32_t N, const float *
             b.n_views++;
         }
         done += b.n_views;
-        { gs_prof_scope prof_(ctx, GS_K_PREPROCESS); hipLaunchKernelGGL(preprocess_batch_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
-                           means, log_scales, quats, sh, opacities, b); }
+        { gs_prof_scope prof_(ctx, GS_K_PREPROCESS);
+          auto kern = pre_fast(b) ? preprocess_batch_kernel<true, true> : preprocess_batch_kernel<true, false>;
+          hipLaunchKernelGGL(kern, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, means, log_scales, quats, sh,
+                             opacities, b); }
         GS_HIP(hipGetLastError());
     }
     return GS_OK;

@@ -244,3 +244,80 @@ def test_blend_forward_with_the_loss_in_its_epilogue(gpu_ctx, kind, W, H):
     torch.cuda.synchronize()
     assert abs(float(la) - float(lb)) <= 3e-6 * float(lb)
     assert float((ga.flat - gb.flat).abs().max()) <= 2e-5 * float(gb.flat.abs().max())
+
+
+def test_k1_fast_form_equals_the_general_form(gpu_ctx, monkeypatch):
+    """K1's batched kernel has a form for launches whose views all have SH degree 3, the strict clip-space centre and
+    a power-of-two tile (constant-folded degree tests, tile divisions as exact multiplications) and a general one;
+    GS_K1_GENERAL=1 forces the general one.  Every output of both batched entry points is bit-identical between
+    the two, near-culled, off-screen and clamped-colour gaussians included; a tile size of 24 takes the general
+    form by itself and must agree with the single-view kernel."""
+    import torch
+    import gsplat_amd as gs
+    cam, R, t, g, rs = synth_scene(40_000, 640, 360, seed=77, fx=300.0, log_scale=(0.5, 3.5))
+    views = [gs.View(cam, R, np.array([0.3 * k, -0.2 * k, 0.6 * k - 4.0])) for k in range(5)]
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    out = {}
+    for form in ("fast", "general"):
+        if form == "general":
+            monkeypatch.setenv("GS_K1_GENERAL", "1")
+        rec = pipe.preprocess_batch(views, records=True)
+        arr = pipe.preprocess_batch(views, records=False)
+        torch.cuda.synchronize()
+        out[form] = ([{k: p[k].clone() for k in ("rec", "depths", "clamped", "rect", "radii")} for p in rec],
+                     [{k: p[k].clone() for k in ("centers", "colors", "conics", "depths", "clamped", "rect", "radii")}
+                      for p in arr])
+    monkeypatch.delenv("GS_K1_GENERAL")
+    for a, b in zip(out["fast"][0] + out["fast"][1], out["general"][0] + out["general"][1]):
+        for k in a:
+            assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), k
+    assert int(out["fast"][0][0]["radii"].count_nonzero()) > 1000
+    assert int(out["fast"][0][0]["clamped"].count_nonzero()) > 0
+    assert int((out["fast"][0][0]["radii"] == 0).sum()) > 0
+    # a tile size that is not a power of two: the launch takes the general form on its own
+    pipe24 = gs.SplatPipeline(g, rs, tile_size=24, opacity_is_logit=False, ctx=gpu_ctx)
+    from gsplat_amd import api
+    pre = pipe24.preprocess_batch(views[:2], records=False)
+    null = ctypes.c_void_p(0)
+    for v, p in zip(views[:2], pre):
+        one = pipe24._alloc_pre(api.make_camera(v.camera, v.camera_r, v.camera_t, pipe24.result_size, 24,
+                                                pipe24.degrees, pipe24.cam_flags))
+        api.check(gpu_ctx.lib.gs_preprocess(
+            gpu_ctx.handle, pipe24.N, api._ptr(pipe24.means), api._ptr(pipe24.log_scales), api._ptr(pipe24.quats),
+            api._ptr(pipe24.sh), ctypes.byref(one["cam"]), api._ptr(one["centers"]), api._ptr(one["depths"]),
+            api._ptr(one["colors"]), api._ptr(one["conics"]), api._ptr(one["clamped"]), api._ptr(one["rect"]),
+            api._ptr(one["radii"]), null, null, null, null, null, null), "gs_preprocess")
+        torch.cuda.synchronize()
+        for k in ("centers", "depths", "colors", "conics", "clamped", "rect", "radii"):
+            assert torch.equal(one[k], p[k]), k
+
+
+def test_k8_fast_form_equals_the_general_form(gpu_ctx, monkeypatch):
+    """K8 has the same two forms as K1 (SH degree 3 and the strict clip-space centre folded in at compile time, or
+    read from the camera); GS_K8_GENERAL=1 forces the general one.  Same gradient rows in, the same parameter
+    gradients out to fp32 rounding (the file is compiled with FMA contraction and the two forms contract differently),
+    for the write and the accumulate call."""
+    import torch
+    import gsplat_amd as gs
+    W, H = 320, 240
+    cam, R, t, g, rs = synth_scene(20_000, W, H, seed=78, fx=200.0, log_scale=(1.0, 3.2))
+    pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx)
+    gen = torch.Generator(device="cpu").manual_seed(78)
+    states = []
+    for v in _views(gs, cam, R, 3):
+        _, st = pipe.forward(v)
+        pipe.backward_rows(st, torch.randn(W, H, 3, generator=gen).to(gpu_ctx.device))
+        states.append(st)
+    out = {}
+    for form in ("fast", "general"):
+        if form == "general":
+            monkeypatch.setenv("GS_K8_GENERAL", "1")
+        grads = gs.FlatGrads(pipe.N, gpu_ctx.device)
+        pipe.backward_params(states, grads, accumulate=False)
+        pipe.backward_params(states[:2], grads, accumulate=True)
+        torch.cuda.synchronize()
+        out[form] = grads.flat.clone()
+    monkeypatch.delenv("GS_K8_GENERAL")
+    scale = float(out["fast"].abs().max())
+    assert scale > 0
+    assert float((out["fast"] - out["general"]).abs().max()) <= 2e-6 * scale
