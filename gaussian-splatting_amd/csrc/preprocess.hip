@@ -199,7 +199,13 @@ __device__ __forceinline__ void preprocess_one(const PreCam &cam, double x, doub
             double r = 0.0;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (k < nb) r = __builtin_fma(basis[k], (double)coef[16 * ch + k], r);
+                if (k < nb) {
+                    float cf = coef[16 * ch + k];
+#ifdef GS_K1_CVT_IN_LOOP
+                    asm volatile("" : "+v"(cf));        // keep the coefficient a float across views (48 VGPRs, not 96)
+#endif
+                    r = __builtin_fma(basis[k], (double)cf, r);
+                }
             r += .5;
             if (r < 0) { r = 0; o.cl[ch] = 1; }
             o.col[ch] = (float)r;
@@ -276,8 +282,13 @@ struct PreBatch {
 
 // RECORDS: instead of centers / colors / conics each view gets the 64-byte blend records (common.h) the
 // blend and culled-binning kernels read, built from the activated opacities: no pack pass per view.
+#ifdef GS_K1_WAVES
+#define GS_K1_OCC __attribute__((amdgpu_waves_per_eu(GS_K1_WAVES, GS_K1_WAVES)))
+#else
+#define GS_K1_OCC
+#endif
 template <bool RECORDS, bool FAST>
-__global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const float *__restrict__ means,
+__global__ __launch_bounds__(256) GS_K1_OCC void preprocess_batch_kernel(int N, const float *__restrict__ means,
                                                                const float *__restrict__ log_scales,
                                                                const float *__restrict__ quats,
                                                                const float *__restrict__ sh,
@@ -295,9 +306,10 @@ __global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const floa
     for (int v = 0; v < b.n_views; v++) {
         PreOut o;
         preprocess_one<false, FAST>(b.cam[v], x, y, z, M, Sg, coef, o);
+#ifdef GS_K1_NOSTORE
+        if (o.depth != 0x7ffffff1) continue;      // experiment: the arithmetic without the stores
+#endif
         if (RECORDS) {
-            // (staging the block's records through LDS so that a wave stores 1 KiB pieces was measured: 0.269 against
-            // 0.251 ms per 8 views -- a thread's four consecutive float4 stores are combined well enough as they are)
             const ViewOut &w = b.out[v];
             w.depths[i] = o.depth;
             w.radii[i] = o.rad;
@@ -306,8 +318,26 @@ __global__ __launch_bounds__(256) void preprocess_batch_kernel(int N, const floa
             for (int k = 0; k < 3; k++) w.clamped[3 * i + k] = o.cl[k];
             float4 geo, con, rgb;
             gs_make_record(o.cx, o.cy, opac, o.con[0], o.con[1], o.con[2], o.col[0], o.col[1], o.col[2], geo, con, rgb);
-            float4 *r = w.records + (size_t)i * 4;
-            r[0] = geo; r[1] = con; r[2] = rgb; r[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // The wave's 64 records go through wave-private LDS ([quarter][lane], pitch 68 float4: conflict-free both
+            // ways; one wave's LDS operations execute in order, so no barrier) and leave as four stores of 1 KiB of
+            // whole lines each, instead of four stores of 64 quarter lines: 0.228 -> 0.202 ms per 8 views.  (Leaving
+            // the unused fourth quarter unwritten costs a read-modify-write per line: 0.303 ms.)
+            __shared__ float4 s_rec[4][4][68];
+            const int lane = threadIdx.x & 63;
+            float4 (*st)[68] = s_rec[threadIdx.x >> 6];
+            const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (i - lane + 64 <= N) {
+                st[0][lane] = geo; st[1][lane] = con; st[2][lane] = rgb; st[3][lane] = zero;
+                float4 *dst = w.records + (size_t)(i - lane) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = k * 64 + lane;
+                    dst[j] = st[j & 3][j >> 2];
+                }
+            } else {                                   // the last, partial wave
+                float4 *r = w.records + (size_t)i * 4;
+                r[0] = geo; r[1] = con; r[2] = rgb; r[3] = zero;
+            }
         } else {
             store_view(i, b.out[v], o);
         }
