@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
     // The thread's 48 SH coefficients are needed once per view: a thread-private copy in LDS (no
     // barrier: nobody else reads it) instead of 12 global loads per view that miss L1 at this
     // occupancy.  [vv][thread] float4: conflict-free for both the write and the reads.
-    __shared__ float4 s_sh4[12][256];
+    // (pitch 261 float4: the transposed reads of the gradient write-out below hit distinct banks)
+    constexpr int SH_PITCH = 261;
+    __shared__ float4 s_sh4[12][SH_PITCH];
     {
         const float4 *sh4 = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
 #pragma unroll
@@ -133,9 +135,16 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
 #pragma unroll 1
     for (int v = 0; v < args.n_views; v++) {
         const PreCam &cam = args.v[v].cam;
+#ifdef GS_K8_NOLOAD
+        Inputs in = nxt;                       // experiment: view 0's inputs for every view (no per-view loads)
+        in.c[0] += (float)v;
+#else
         const Inputs in = nxt;
+#endif
         const int degree = FAST ? 3 : cam.degree;
+#ifndef GS_K8_NOLOAD
         if (v + 1 < args.n_views) nxt = fetch(v + 1);
+#endif
         if (in.radius <= 0) continue;
         any = true;
         g_op += in.d_op;
@@ -321,25 +330,55 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
         }
     }
 
+#ifdef GS_K8_NOSTORE
+    if (g_op != 123456.0f) return;         // experiment: everything but the stores
+#endif
+    // The SH gradients of a full wave (64 x 192 B, contiguous) leave through the wave's columns of s_sh4, whose
+    // coefficients are no longer needed: twelve stores of 1 KiB of whole lines instead of twelve stores of 64 quarter
+    // lines 192 B apart (one wave's LDS operations execute in order: no barrier).
+    const int lane = threadIdx.x & 63;
+    const bool full_wave = i - lane + 64 <= N;
+    const bool wave_any = __ballot(any) != 0;
+    if (full_wave && (wave_any || !accumulate)) {
+#pragma unroll
+        for (int vv = 0; vv < 12; vv++)
+            s_sh4[vv][threadIdx.x] = make_float4(acc_sh[4 * vv], acc_sh[4 * vv + 1], acc_sh[4 * vv + 2], acc_sh[4 * vv + 3]);
+        float4 *dst = reinterpret_cast<float4 *>(dL_dsh + (size_t)(i - lane) * 48);
+        const int col0 = threadIdx.x - lane;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int j = k * 64 + lane;                 // float4 j of the wave's 768: gaussian j / 12, quarter j % 12
+            float4 w = s_sh4[j % 12][col0 + j / 12];
+            if (accumulate) {
+                const float4 old = dst[j];
+                w.x += old.x; w.y += old.y; w.z += old.z; w.w += old.w;
+            }
+            dst[j] = w;
+        }
+    }
     if (accumulate) {
         if (any) {
             for (int k = 0; k < 3; k++) { dL_dmeans[3 * i + k] += (float)g_mean[k]; dL_dlog_scales[3 * i + k] += (float)g_ls[k]; }
             for (int k = 0; k < 4; k++) dL_dquats[4 * i + k] += (float)g_q[k];
             if (ROWS && dL_dopacity) dL_dopacity[i] += g_op;
+            if (!full_wave) {
 #pragma unroll
-            for (int vv = 0; vv < 12; vv++) {
-                float4 w = out_sh[vv];
-                w.x += acc_sh[4 * vv]; w.y += acc_sh[4 * vv + 1]; w.z += acc_sh[4 * vv + 2]; w.w += acc_sh[4 * vv + 3];
-                out_sh[vv] = w;
+                for (int vv = 0; vv < 12; vv++) {
+                    float4 w = out_sh[vv];
+                    w.x += acc_sh[4 * vv]; w.y += acc_sh[4 * vv + 1]; w.z += acc_sh[4 * vv + 2]; w.w += acc_sh[4 * vv + 3];
+                    out_sh[vv] = w;
+                }
             }
         }
     } else {
         for (int k = 0; k < 3; k++) { dL_dmeans[3 * i + k] = (float)g_mean[k]; dL_dlog_scales[3 * i + k] = (float)g_ls[k]; }
         for (int k = 0; k < 4; k++) dL_dquats[4 * i + k] = (float)g_q[k];
         if (ROWS && dL_dopacity) dL_dopacity[i] = g_op;
+        if (!full_wave) {
 #pragma unroll
-        for (int vv = 0; vv < 12; vv++)
-            out_sh[vv] = make_float4(acc_sh[4 * vv], acc_sh[4 * vv + 1], acc_sh[4 * vv + 2], acc_sh[4 * vv + 3]);
+            for (int vv = 0; vv < 12; vv++)
+                out_sh[vv] = make_float4(acc_sh[4 * vv], acc_sh[4 * vv + 1], acc_sh[4 * vv + 2], acc_sh[4 * vv + 3]);
+        }
     }
 }
 
