@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256, GS_K8_WAVES) void param_bwd_kernel(
         for (int c = r; c < 3; c++)
             Sg[3 * r + c] = Sg[3 * c + r] = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2];
 
-    // per-view inputs, fetched one view ahead of their use (two HBM round trips per view otherwise)
+    // per-view inputs, fetched one view ahead of their use (two HBM round trips per view otherwise).  (Staging a wave's
+    // 64 rows per view through LDS with three whole-row LDS-DMA loads instead of these register loads of quarter
+    // lines was measured: 0.266 against 0.230 ms per 8 views -- the wait for the DMA sits in front of every view.)
     struct Inputs {
         int radius;
         float c[2], con[3], col[3], d_op;

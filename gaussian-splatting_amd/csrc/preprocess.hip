@@ -297,6 +297,8 @@ __global__ __launch_bounds__(256) GS_K1_OCC void preprocess_batch_kernel(int N, 
     if (i >= N) return;
     double x, y, z, q[4];
     float ls[3], coef[48];
+    // (the SH coefficients as twelve coalesced 1 KiB loads through wave-private LDS instead of twelve loads of 64
+    // quarter lines: 0.190 against 0.191 ms per 8 views -- the loads are not what the kernel waits for)
     load_params(i, means, log_scales, quats, sh, x, y, z, q, ls, coef);
     const float opac = RECORDS ? opacities[i] : 0.0f;
     // M and Sigma once per gaussian: the host has checked that the views share scale_mod and the scale switch
