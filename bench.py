@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_SUMMARY = "r03_pmc_summary.json"
+# counter summaries of other workloads (tools/pmc_collect.sh with GS_N / GS_W / GS_H / GS_LS* / GS_LISTS): the one whose
+# source hash and workload match the run is used
+PMC_SUMMARIES = (PMC_SUMMARY, "r03_pmc_summary_culled.json", "r03_pmc_summary_10m4k.json")
 # stages whose launch is several kernels: the counters of the stage are the sums over its parts
 PMC_PARTS = {"bin_sort": ("tile_hist", "tile_hist2", "tile_scatter")}     # (+ the 256-block scans, not separable by name)
 LISTS_NOTE = {
@@ -286,19 +289,24 @@ def main():
         dom = max(timed, key=lambda k: timed[k][0]) if timed else None
     # HBM bytes and instruction counts per launch from the PMC passes of THIS source tree on THIS workload
     # (tools/pmc_collect.sh, tools/pmc_summary.py): refused when the kernels have changed since, or for another one
-    pmc, pmc_why = None, None
-    try:
-        cand = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
+    pmc, pmc_why, pmc_file, reasons = None, None, None, []
+    for name in PMC_SUMMARIES:
+        try:
+            cand = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
         meta = cand.get("_meta", {})
         if meta.get("source_sha16") != source_sha16():
-            pmc_why = f"none: profiles/{PMC_SUMMARY} was collected from another source tree"
+            reasons.append(f"{name}: another source tree")
         elif (meta.get("gaussians", 1_000_000), meta.get("width", 1920), meta.get("height", 1080)) != (N, W, H) or \
                 tuple(meta.get("log_scale", (1.0, 3.0))) != tuple(args.log_scale) or meta.get("lists", "culled") != args.lists:
-            pmc_why = f"none: profiles/{PMC_SUMMARY} was collected on another workload"
+            reasons.append(f"{name}: another workload")
         else:
-            pmc = cand
-    except (OSError, ValueError):
-        pmc_why = f"none: no profiles/{PMC_SUMMARY}"
+            pmc, pmc_file = cand, name
+            break
+    if pmc is None:
+        pmc_why = "none: no counter summary under profiles/ for this source tree and workload (" + \
+                  ("; ".join(reasons) or "no file") + ")"
 
     def stage_record(k):
         """roofline record of one stage: algorithmic bytes / its duration ALONE on the chip against HBM peak, plus
@@ -327,7 +335,7 @@ def main():
                             e[name] = e.get(name, 0.0) + q[name] * w
         if e and "hbm_traffic_bytes" in e:
             r["traffic"] = int(e["hbm_traffic_bytes"])
-            r["traffic_source"] = f"profiles/{PMC_SUMMARY} (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+            r["traffic_source"] = f"profiles/{pmc_file} (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
         elif pmc_why:
             r["traffic_source"] = pmc_why
         if e and e.get("GRBM_GUI_ACTIVE") and "SQ_INSTS_VALU" in e:

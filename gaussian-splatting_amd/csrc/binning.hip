@@ -67,6 +67,41 @@ __global__ __launch_bounds__(SCAN_THREADS) void count_kernel(int N, const int4 *
     }
 }
 
+// K2 in depth order (large scenes, SortedAux in binning_kernels.h): counts[i] and the clipped rect of gaussian perm[i]
+__global__ __launch_bounds__(SCAN_THREADS) void count_sorted_kernel(int N, const int32_t *__restrict__ perm,
+                                                                    const int4 *__restrict__ rect,
+                                                                    const int32_t *__restrict__ depth, Grid grid,
+                                                                    uint32_t *__restrict__ counts, int4 *__restrict__ info,
+                                                                    ulonglong2 *__restrict__ partials) {
+    __shared__ uint32_t s_max[SCAN_THREADS / 64];
+    __shared__ unsigned long long s_sum[SCAN_THREADS / 64];
+    unsigned long long c = 0;
+    uint32_t md = 0;
+    for (int i = blockIdx.x * SCAN_THREADS + threadIdx.x; i < N; i += COUNT_BLOCKS * SCAN_THREADS) {
+        const int g = perm[i];
+        int x0, y0, h;
+        const int d = depth[g];
+        const uint32_t cg = tile_count(rect[g], d, grid, x0, y0, h);
+        counts[i] = cg;
+        info[i] = make_int4(x0 | (int)((cg ? cg / (uint32_t)h : 0u) << 16), y0, h, g);
+        c += cg;
+        if (cg) md = max(md, (uint32_t)d);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        c += __shfl_xor(c, o, 64);
+        md = max(md, (uint32_t)__shfl_xor((int)md, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = md; s_sum[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        unsigned long long sum = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; w++) { m = max(m, s_max[w]); sum += s_sum[w]; }
+        partials[blockIdx.x] = make_ulonglong2(sum, m);
+    }
+}
+
 __global__ __launch_bounds__(COUNT_BLOCKS) void count_total_kernel(const ulonglong2 *__restrict__ partials,
                                                                    unsigned long long *__restrict__ total) {
     __shared__ unsigned long long s_sum[COUNT_BLOCKS / 64];
@@ -97,7 +132,7 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
                                                         const int4 *__restrict__ rect,
                                                         const int32_t *__restrict__ depth, Grid grid,
                                                         const uint32_t *__restrict__ offsets, uint32_t D,
-                                                        uint2 *__restrict__ pairs) {
+                                                        uint2 *__restrict__ pairs, const int4 *__restrict__ info) {
     __shared__ uint32_t s_first[4][64];  // exclusive prefix of counts within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
     __shared__ uint32_t s_mark[4][64];
@@ -106,7 +141,11 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
     const int i = i0 + lane;
     uint32_t cnt = 0;
     int x0 = 0, y0 = 0, h = 1, g = 0;
-    if (i < N) {
+    if (i < N && info) {             // large scenes: the clipped rects in depth order, left by count_sorted_kernel
+        const int4 inf = info[i];
+        x0 = inf.x & 0xFFFF; y0 = inf.y; h = inf.z; g = inf.w;
+        cnt = (uint32_t)(inf.x >> 16) * (uint32_t)h;
+    } else if (i < N) {
         g = perm[i];
         // perm may be the caller's array (gs_bin_fill_prepared): an id that is not a gaussian owns no pair
         if ((uint32_t)g < (uint32_t)N) cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
@@ -175,15 +214,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void sorted_offsets_kernel(int N, con
                                                                       uint32_t *__restrict__ offsets) {
     sorted_offsets_body(blockIdx.x, N, perm, counts, block_offsets, offsets);
 }
-template <bool CULL_EMIT>
+template <int MODE>
 __global__ __launch_bounds__(256) void culled_pairs_kernel(int N, const int32_t *__restrict__ perm,
                                                            const int4 *__restrict__ rect,
                                                            const int32_t *__restrict__ depth, Grid grid,
                                                            const float4 *__restrict__ rec, CullBox cb,
                                                            uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ offsets, uint32_t D,
-                                                           uint2 *__restrict__ pairs) {
-    culled_pairs_body<CULL_EMIT>(blockIdx.x, N, perm, rect, depth, grid, rec, cb, counts, offsets, D, pairs);
+                                                           uint2 *__restrict__ pairs, SortedAux aux) {
+    culled_pairs_body<MODE>(blockIdx.x, N, perm, rect, depth, grid, rec, cb, counts, offsets, D, pairs, aux);
 }
 template <int THREADS, bool PAIRS>
 __global__ __launch_bounds__(THREADS) void radix_hist_kernel(uint32_t n, const uint32_t *__restrict__ keys,
@@ -329,8 +368,40 @@ int gs_radix_sort_pairs(gs_ctx *ctx, uint32_t n, const uint32_t *keys_in, const 
 
 namespace {
 
+// K4a: gaussians into (u32(depth), id) order, the low `depth_bits` bits of the key (the bits max(depth) occupies)
+int bin_depth_sort(gs_ctx *ctx, int32_t N, const int32_t *depths, int depth_bits, const int32_t **perm_out) {
+    int rc;
+    const size_t n4 = ((size_t)N * 4 + 255) & ~(size_t)255;
+    if ((rc = gs_buf_reserve(ctx, &ctx->depth_sort, 4 * n4))) return rc;
+    char *ds = (char *)ctx->depth_sort.p;
+    uint32_t *dk[2] = {(uint32_t *)ds, (uint32_t *)(ds + n4)};
+    int32_t *dv[2] = {(int32_t *)(ds + 2 * n4), (int32_t *)(ds + 3 * n4)};
+    const int depth_passes = (depth_bits + 7) / 8 > 0 ? (depth_bits + 7) / 8 : 1;
+    gs_prof_scope prof_(ctx, GS_K_DEPTH_SORT);
+    const uint32_t *kin = reinterpret_cast<const uint32_t *>(depths);
+    const int32_t *vin = nullptr;
+    for (int p = 0; p < depth_passes; p++) {
+        const bool last = p == depth_passes - 1;
+        const int nbits = last ? (depth_bits - 8 * p > 0 ? depth_bits - 8 * p : 1) : 8;
+        if ((rc = radix_pass(ctx, (uint32_t)N, soa_io(kin, vin, last ? nullptr : dk[p & 1], dv[p & 1]), RADIX_SOA, 8 * p, nbits)))
+            return rc;
+        kin = dk[p & 1];
+        vin = dv[p & 1];
+    }
+    *perm_out = vin;
+    return GS_OK;
+}
+
+SortedAux sorted_aux(gs_ctx *ctx, int32_t N) {
+    char *base = (char *)ctx->sorted_aux.p;
+    const size_t n16 = (size_t)N * 16;
+    return SortedAux{(int4 *)base, (float4 *)(base + n16), (float4 *)(base + 2 * n16)};
+}
+
 // rec == nullptr: the reference's rect semantics; otherwise pairs are culled with the box test.
 // Launches the count and the copy of (D, max depth) to pinned memory, and records count_event.
+// From ctx->sorted_count_from gaussians on (option sorted_count_from; SortedAux in binning_kernels.h) the depth
+// sort runs here, over all 32 key bits (max(depth) is not known yet), and the count walks the gaussians in that order.
 int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths, int32_t res_w,
                     int32_t res_h, int32_t tile_size, const float4 *rec, float pixel_offset) {
     int rc;
@@ -352,13 +423,36 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
     if ((rc = gs_buf_reserve(ctx, &ctx->total, 16 + COUNT_BLOCKS * sizeof(ulonglong2)))) return rc;
     if (!ctx->count_event) GS_HIP(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
     ulonglong2 *partials = (ulonglong2 *)((char *)ctx->total.p + 16);
-    {
+    ctx->count_sorted = N >= ctx->sorted_count_from;
+    if (ctx->count_sorted) {
+        const int32_t *perm = nullptr;
+        if ((rc = bin_depth_sort(ctx, N, depths, 32, &perm))) return rc;
+        if ((rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 48))) return rc;
+        const SortedAux aux = sorted_aux(ctx, N);
         gs_prof_scope prof_(ctx, GS_K_COUNT);
         if (rec) {
             const CullBox cb{(float)tile_size, pixel_offset};
-            hipLaunchKernelGGL(culled_pairs_kernel<false>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+            hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_COUNT_SORTED>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+                               perm, reinterpret_cast<const int4 *>(tiles_touched), depths, grid, rec, cb,
+                               (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr, aux);
+            // (D only: the depth read beside a count belongs to another gaussian here, and max(depth) is not needed)
+            hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
+                               (const uint32_t *)ctx->counts.p, depths, partials);
+        } else {
+            hipLaunchKernelGGL(count_sorted_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N, perm,
+                               reinterpret_cast<const int4 *>(tiles_touched), depths, grid, (uint32_t *)ctx->counts.p,
+                               aux.info, partials);
+        }
+        hipLaunchKernelGGL(count_total_kernel, dim3(1), dim3(COUNT_BLOCKS), 0, ctx->stream,
+                           (const ulonglong2 *)partials, (unsigned long long *)ctx->total.p);
+    } else {
+        gs_prof_scope prof_(ctx, GS_K_COUNT);
+        if (rec) {
+            const CullBox cb{(float)tile_size, pixel_offset};
+            hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_COUNT>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                                (const int32_t *)nullptr, reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
-                               rec, cb, (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr);
+                               rec, cb, (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr,
+                               SortedAux{});
             hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
                                (const uint32_t *)ctx->counts.p, depths, partials);
         } else {
@@ -403,6 +497,7 @@ int bin_count_end(gs_ctx *ctx, int64_t *D_host) {
 
 // K3 + K4b + K5 of one view: pairs emitted in depth order (perm) at the scanned offsets, a stable sort by tile id
 // alone, tile ranges.  `ranges` has been zeroed by the caller; D > 0.
+// perm == nullptr: the gaussians' summaries in depth order are in ctx->sorted_aux (bin_count_begin's sorted form)
 int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depths, Grid grid, const float4 *rec,
                   int32_t tile_size, float pixel_offset, const int32_t *perm, const uint32_t *offsets, int64_t D,
                   uint64_t *keys, int32_t *vals, int32_t *ranges) {
@@ -430,13 +525,18 @@ int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depth
     }
     {
         gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
+        const SortedAux aux = perm ? SortedAux{} : sorted_aux(ctx, N);
         if (rec) {
             const CullBox cb{(float)tile_size, pixel_offset};
-            hipLaunchKernelGGL(culled_pairs_kernel<true>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm,
-                               rect, depths, grid, rec, cb, (uint32_t *)nullptr, offsets, (uint32_t)D, pp[0]);
+            if (perm)
+                hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_EMIT>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm,
+                                   rect, depths, grid, rec, cb, (uint32_t *)nullptr, offsets, (uint32_t)D, pp[0], aux);
+            else
+                hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_EMIT_AUX>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+                                   perm, rect, depths, grid, rec, cb, (uint32_t *)nullptr, offsets, (uint32_t)D, pp[0], aux);
         } else {
             hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm, rect,
-                               depths, grid, offsets, (uint32_t)D, pp[0]);
+                               depths, grid, offsets, (uint32_t)D, pp[0], (const int4 *)aux.info);
         }
     }
     GS_HIP(hipGetLastError());
@@ -493,31 +593,11 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     if (D == 0) return GS_OK;
     GS_REQUIRE(vals, "gs_bin_fill: vals is NULL with D=%lld", (long long)D);
     const int4 *rect = reinterpret_cast<const int4 *>(tiles_touched);
-    const size_t n4 = ((size_t)N * 4 + 255) & ~(size_t)255;
-
-    // K4a: gaussians into (u32(depth), id) order; only the bytes max(depth) occupies are sorted
-    if ((rc = gs_buf_reserve(ctx, &ctx->depth_sort, 4 * n4))) return rc;
-    char *ds = (char *)ctx->depth_sort.p;
-    uint32_t *dk[2] = {(uint32_t *)ds, (uint32_t *)(ds + n4)};
-    int32_t *dv[2] = {(int32_t *)(ds + 2 * n4), (int32_t *)(ds + 3 * n4)};
-    const int depth_bits = bits_of(ctx->bin_max_depth);
-    const int depth_passes = (depth_bits + 7) / 8 > 0 ? (depth_bits + 7) / 8 : 1;
+    // K4a: gaussians into (u32(depth), id) order; only the bytes max(depth) occupies are sorted.  (Done already, and
+    // the counts are in that order, when the count ran in its sorted form: perm stays NULL for the kernels below.)
     const int32_t *perm = nullptr;
-    {
-        gs_prof_scope prof_(ctx, GS_K_DEPTH_SORT);
-        const uint32_t *kin = reinterpret_cast<const uint32_t *>(depths);
-        const int32_t *vin = nullptr;
-        for (int p = 0; p < depth_passes; p++) {
-            const bool last = p == depth_passes - 1;
-            const int nbits = last ? (depth_bits - 8 * p > 0 ? depth_bits - 8 * p : 1) : 8;
-            if ((rc = radix_pass(ctx, (uint32_t)N, soa_io(kin, vin, last ? nullptr : dk[p & 1], dv[p & 1]), RADIX_SOA, 8 * p,
-                                 nbits)))
-                return rc;
-            kin = dk[p & 1];
-            vin = dv[p & 1];
-        }
-        perm = vin;
-    }
+    if (!ctx->count_sorted)
+        if ((rc = bin_depth_sort(ctx, N, depths, bits_of(ctx->bin_max_depth), &perm))) return rc;
 
     // K2': exclusive offsets of tiles-per-gaussian in depth order
     const int nblocks = gs_div_up(N, SCAN_TILE);
@@ -572,6 +652,7 @@ extern "C" int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t
         {&ctx->bounds, batch_views ? (size_t)GS_BIN_MAX_VIEWS * 256 * sizeof(ulonglong2) + 2 * GS_BIN_MAX_VIEWS * 8 : 0},
         {&ctx->tile_order_buf, blocks16 * 2 * sizeof(int32_t)},
         {&ctx->tile_counts, (size_t)gs_div_up(res_w, tile_size) * gs_div_up(res_h, tile_size) * 4}, {&ctx->loss_partials, 1024 * sizeof(double)},
+        {&ctx->sorted_aux, N_max >= ctx->sorted_count_from ? N * 48 : 0},
         {&ctx->packed, array_api ? N * 64 : 0}, {&ctx->grad_rows, array_api ? N * 64 : 0}};
     for (auto &w : want)
         if (w.bytes)

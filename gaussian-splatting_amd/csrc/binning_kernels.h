@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t slot_owner(uint32_t *mark_row, int lane, uin
     return m - 1u;                    // a slot below the wave's total always has an owner (m >= 1)
 }
 
-// K2'a: per-block totals of counts taken in depth order
+// K2'a: per-block totals of counts taken in depth order (perm == nullptr: the counts are in that order already)
 __device__ __forceinline__ void sorted_block_sums_body(int bid, int N, const int32_t *__restrict__ perm,
                                                                          const uint32_t *__restrict__ counts,
                                                                          uint32_t *__restrict__ block_sums) {
@@ -108,7 +108,7 @@ __device__ __forceinline__ void sorted_block_sums_body(int bid, int N, const int
     uint32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++)
-        if (base + k < N) sum += counts[perm[base + k]];
+        if (base + k < N) sum += counts[perm ? perm[base + k] : base + k];
     uint32_t total;
     block_exclusive_scan(sum, &total);
     if (threadIdx.x == 0) block_sums[bid] = total;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void sorted_offsets_body(int bid, int N, const int32_
     uint32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        c[k] = (base + k < N) ? counts[perm[base + k]] : 0u;
+        c[k] = (base + k < N) ? counts[perm ? perm[base + k] : base + k] : 0u;
         sum += c[k];
     }
     uint32_t total;
@@ -185,14 +185,29 @@ __device__ __forceinline__ bool pair_may_contribute(const float4 geo, const floa
 // serialise its wave.  CULL_EMIT = false: counts[g] <- pairs that pass.  CULL_EMIT = true (gaussians taken
 // in depth order through perm): the passing pairs are written as {tile id, gaussian} from offsets[first position
 // of the wave] on, compacted with a ballot, i.e. in (depth order, tile order).
-template <bool CULL_EMIT>
+//
+// Large scenes (SortedAux, modes 2 and 3): once rect / depth / records of all gaussians no longer fit the caches, the
+// gathers in depth order cost a 128-byte line per 16-byte item, twice (count + scan read counts[perm[i]], emit reads
+// rect / depth / record of perm[i]).  There the depth sort runs FIRST and the count walks the gaussians in depth
+// order: it gathers once, leaves counts[] in that order (the scans stream it) and a 48-byte summary per gaussian
+// (clipped rect, id, the two record quarters of the box test) that the emit pass streams instead of gathering again.
+struct SortedAux {
+    int4 *info;      // x0 | w << 16, y0, h, gaussian
+    float4 *geo;     // record quarter 0 (culled lists only)
+    float4 *con;     // record quarter 1
+};
+
+enum { PAIRS_COUNT = 0, PAIRS_EMIT = 1, PAIRS_COUNT_SORTED = 2, PAIRS_EMIT_AUX = 3 };
+
+template <int MODE>
 __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t *__restrict__ perm,
                                                            const int4 *__restrict__ rect,
                                                            const int32_t *__restrict__ depth, Grid grid,
                                                            const float4 *__restrict__ rec, CullBox cb,
                                                            uint32_t *__restrict__ counts,
                                                            const uint32_t *__restrict__ offsets, uint32_t D,
-                                                           uint2 *__restrict__ pairs) {
+                                                           uint2 *__restrict__ pairs, SortedAux aux = SortedAux{}) {
+    constexpr bool CULL_EMIT = MODE == PAIRS_EMIT || MODE == PAIRS_EMIT_AUX;
     __shared__ uint32_t s_first[4][64];  // exclusive prefix of rect sizes within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
     __shared__ float4 s_geo[4][64], s_con[4][64];
@@ -204,14 +219,30 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
     uint32_t cnt = 0;
     int x0 = 0, y0 = 0, h = 1, g = 0;
     float4 geo = make_float4(0.f, 0.f, 0.f, 0.f), con = geo;
-    if (i < N) {
-        g = CULL_EMIT ? perm[i] : i;
+    if (MODE == PAIRS_EMIT_AUX) {
+        if (i < N) {
+            const int4 inf = aux.info[i];
+            x0 = inf.x & 0xFFFF; y0 = inf.y; h = inf.z; g = inf.w;
+            cnt = (uint32_t)(inf.x >> 16) * (uint32_t)h;
+            if (cnt) {
+                geo = aux.geo[i];
+                con = aux.con[i];
+            }
+        }
+    } else if (i < N) {
+        g = MODE == PAIRS_COUNT ? i : perm[i];
         // perm may be the caller's array (gs_bin_fill_prepared): an id that is not a gaussian owns no pair
         if ((uint32_t)g < (uint32_t)N) cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
         else g = 0;
         if (cnt) {
             geo = rec[(size_t)g * 4];
             con = rec[(size_t)g * 4 + 1];
+        }
+        if (MODE == PAIRS_COUNT_SORTED) {
+            const uint32_t w = cnt ? cnt / (uint32_t)h : 0u;      // cnt = w * h; no pair: w = 0
+            aux.info[i] = make_int4(x0 | (int)(w << 16), y0, h, g);
+            aux.geo[i] = geo;
+            aux.con[i] = con;
         }
     }
     const uint32_t inc = wave_inclusive_scan(cnt);

@@ -82,6 +82,11 @@ struct gs_ctx {
     gs_buf tile_order_buf;            // i32[ntiles] launch order + i32[ntiles] work per tile
     gs_buf tile_counts;               // u32[tiles] pairs per tile (first pass of the tile sort -> K5)
     bool tile_hist = true;            // option tile_histogram: K5 from that histogram instead of the sorted tile ids
+    // option sorted_count_from: from this many gaussians on the depth sort runs before the tile count and the count,
+    // scan and emit kernels stream depth-ordered arrays instead of gathering (binning_kernels.h, SortedAux)
+    int32_t sorted_count_from = 2 << 20;
+    bool count_sorted = false;        // the pending / last count of this ctx ran in that form
+    gs_buf sorted_aux;                // 48 B per gaussian: clipped rect + id, two record quarters, in depth order
     int32_t bin_N = -1;
     int64_t bin_D = -1;
     uint32_t bin_max_depth = 0;

@@ -102,6 +102,7 @@ extern "C" int gs_ctx_create(int device, void *stream, gs_ctx **out) {
         return gs_set_error(GS_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
     }
     if (const char *e = getenv("GSPLAT_TILE_ORDER")) c->tile_order = atoi(e) != 0;
+    if (const char *e = getenv("GSPLAT_SORTED_COUNT_FROM")) c->sorted_count_from = atoi(e) >= 0 ? atoi(e) : c->sorted_count_from;
     if (const char *e = getenv("GSPLAT_PPT")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4) c->ppt = v;
@@ -130,6 +131,11 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
     if (strcmp(name, "tile_histogram") == 0) {
         GS_REQUIRE(value == 0 || value == 1, "tile_histogram must be 0 or 1 (got %d)", value);
         ctx->tile_hist = value != 0;
+        return GS_OK;
+    }
+    if (strcmp(name, "sorted_count_from") == 0) {   // gaussians from which the count runs in depth order (0: always)
+        GS_REQUIRE(value >= 0, "sorted_count_from must be >= 0 (got %d)", value);
+        ctx->sorted_count_from = value;
         return GS_OK;
     }
     if (strcmp(name, "profile_mask") == 0) {   // bit i: time kernel id i (gs_profile_kernel_name) when profiling is on
@@ -228,7 +234,7 @@ extern "C" int gs_ctx_destroy(gs_ctx *ctx) {
     gs_buf *bufs[] = {&ctx->counts, &ctx->offsets, &ctx->block_sums, &ctx->total, &ctx->depth_sort,
                       &ctx->keys_tmp, &ctx->vals_tmp, &ctx->radix_table, &ctx->packed, &ctx->grad_rows,
                       &ctx->tile_scratch, &ctx->loss_partials, &ctx->stats_words, &ctx->det_partials, &ctx->det_sort,
-                      &ctx->tile_order_buf, &ctx->bounds, &ctx->tile_counts};
+                      &ctx->tile_order_buf, &ctx->bounds, &ctx->tile_counts, &ctx->sorted_aux};
     for (gs_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (gs_prof_span &sp : ctx->prof_spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }

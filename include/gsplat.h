@@ -83,7 +83,12 @@ int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t res_w, int
  * of 2048..16384 blocks; results are unchanged (float atomics arrive in another order).
  * "tile_histogram": 1 (default) = gs_bin_fill* take the tile ranges from a per-tile histogram counted in the first
  * pass of the tile sort (frames of up to 32 768 tiles, keys == NULL) instead of writing the sorted tile ids and
- * reading them back; 0 = always the latter.  Same ranges bit for bit. */
+ * reading them back; 0 = always the latter.  Same ranges bit for bit.
+ * "sorted_count_from": gaussians from which gs_bin_count*_begin sorts by depth FIRST (all 32 key bits) and counts in
+ * that order, so that the scan and emit kernels of gs_bin_fill* stream depth-ordered arrays (48 bytes of workspace
+ * per gaussian) instead of gathering rect / depth / record per gaussian again -- once those arrays outgrow the caches a
+ * gather costs a 128-byte line per item.  Default 2 097 152 (also GSPLAT_SORTED_COUNT_FROM); 0 = always.  Same lists
+ * bit for bit. */
 int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value);
 /* Per-kernel timing with HIP events on the ctx stream (no reference counterpart; the reference
  * only prints perf_counter deltas per stage, train.py:29-60).  While enabled every kernel launch

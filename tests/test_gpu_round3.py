@@ -321,3 +321,55 @@ def test_k8_fast_form_equals_the_general_form(gpu_ctx, monkeypatch):
     scale = float(out["fast"].abs().max())
     assert scale > 0
     assert float((out["fast"] - out["general"]).abs().max()) <= 2e-6 * scale
+
+
+def test_sorted_count_form_gives_the_same_lists(gpu_ctx):
+    """From `sorted_count_from` gaussians on the depth sort runs before the tile count and count / scan / emit stream
+    depth-ordered arrays (large scenes); sorted_count_from = 0 forces that form at any size.  Keys, values and ranges
+    are bit-identical to the default form: random rects incl. degenerate and off-grid ones, zero / tied / wrapped
+    (negative) depths, the 64-bit keys, and the culled lists of a synthetic scene through the pipeline."""
+    import torch
+    import gsplat_amd as gs
+    rng = np.random.default_rng(77)
+    cases = []
+    for case in range(16):
+        N = int(rng.choice([1, 63, 64, 65, 1000, 4097, 20000]))
+        ts = int(rng.choice([8, 16, 32]))
+        W, H = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        tx_n, ty_n = -(-W // ts), -(-H // ts)
+        x0 = rng.integers(-2, tx_n + 2, N); y0 = rng.integers(-2, ty_n + 2, N)
+        x1 = x0 + rng.integers(-1, 6, N); y1 = y0 + rng.integers(-1, 6, N)
+        tt = np.stack([np.stack([x0, y0], 1), np.stack([x1, y1], 1)], 1).astype(np.int32)
+        dep = [rng.integers(0, 40, N), rng.integers(2000, 60000, N), rng.integers(0, 2**24, N),
+               rng.integers(-2**31, 2**31, N)][case % 4].astype(np.int32)
+        cases.append((tt, dep, [W, H], ts))
+    cam, R, t, g, rs = synth_scene(30_000, 640, 360, seed=79, fx=300.0, log_scale=(1.0, 3.3))
+    views = _views(gs, cam, R, 2)
+
+    def run():
+        out = []
+        for tt, dep, rs_, ts in cases:
+            b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, np.ones(len(dep)), dep, result_size=rs_, tile_size=ts)
+            out.append((b.D, b.keys.cpu().numpy().copy() if b.D else None, b.vals.cpu().numpy().copy() if b.D else None,
+                        b.ranges.cpu().numpy().copy()))
+        for cull in (False, True):
+            pipe = gs.SplatPipeline(g, rs, opacity_is_logit=False, ctx=gpu_ctx, cull_tiles=cull)
+            for v in views:
+                image, st = pipe.forward(v)
+                torch.cuda.synchronize()
+                b = st["binning"]
+                out.append((b.D, None, b.vals.cpu().numpy().copy(), b.ranges.cpu().numpy().copy(), image.cpu().numpy().copy()))
+        return out
+
+    ref = run()
+    gpu_ctx.set_option("sorted_count_from", 0)
+    try:
+        got = run()
+    finally:
+        gpu_ctx.set_option("sorted_count_from", 2 << 20)
+    assert len(ref) == len(got)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert a[0] == b[0], k
+        for x, y in zip(a[1:], b[1:]):
+            assert (x is None and y is None) or np.array_equal(x, y), k
+    assert sum(a[0] for a in ref) > 100_000
