@@ -395,7 +395,7 @@ int bin_depth_sort(gs_ctx *ctx, int32_t N, const int32_t *depths, int depth_bits
 SortedAux sorted_aux(gs_ctx *ctx, int32_t N) {
     char *base = (char *)ctx->sorted_aux.p;
     const size_t n16 = (size_t)N * 16;
-    return SortedAux{(int4 *)base, (float4 *)(base + n16), (float4 *)(base + 2 * n16)};
+    return SortedAux{(int4 *)base, (float4 *)(base + n16), (float4 *)(base + 2 * n16), (uint2 *)(base + 3 * n16)};
 }
 
 // rec == nullptr: the reference's rect semantics; otherwise pairs are culled with the box test.
@@ -427,7 +427,7 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
     if (ctx->count_sorted) {
         const int32_t *perm = nullptr;
         if ((rc = bin_depth_sort(ctx, N, depths, 32, &perm))) return rc;
-        if ((rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 48))) return rc;
+        if ((rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 56))) return rc;
         const SortedAux aux = sorted_aux(ctx, N);
         gs_prof_scope prof_(ctx, GS_K_COUNT);
         if (rec) {
@@ -446,13 +446,15 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
         hipLaunchKernelGGL(count_total_kernel, dim3(1), dim3(COUNT_BLOCKS), 0, ctx->stream,
                            (const ulonglong2 *)partials, (unsigned long long *)ctx->total.p);
     } else {
+        if (rec && (rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 8))) return rc;
         gs_prof_scope prof_(ctx, GS_K_COUNT);
         if (rec) {
             const CullBox cb{(float)tile_size, pixel_offset};
+            // (the buffer holds only the per-gaussian test masks in this form)
             hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_COUNT>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                                (const int32_t *)nullptr, reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
                                rec, cb, (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr,
-                               SortedAux{});
+                               SortedAux{nullptr, nullptr, nullptr, (uint2 *)ctx->sorted_aux.p});
             hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
                                (const uint32_t *)ctx->counts.p, depths, partials);
         } else {
@@ -500,7 +502,7 @@ int bin_count_end(gs_ctx *ctx, int64_t *D_host) {
 // perm == nullptr: the gaussians' summaries in depth order are in ctx->sorted_aux (bin_count_begin's sorted form)
 int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depths, Grid grid, const float4 *rec,
                   int32_t tile_size, float pixel_offset, const int32_t *perm, const uint32_t *offsets, int64_t D,
-                  uint64_t *keys, int32_t *vals, int32_t *ranges) {
+                  uint64_t *keys, int32_t *vals, int32_t *ranges, const uint2 *masks = nullptr) {
     int rc;
     const int tiles = grid.tiles_x * grid.tiles_y;
     const size_t d4 = ((size_t)D * 4 + 255) & ~(size_t)255;
@@ -525,7 +527,8 @@ int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depth
     }
     {
         gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
-        const SortedAux aux = perm ? SortedAux{} : sorted_aux(ctx, N);
+        // masks: the test outcomes of this ctx's own culled count (gaussian order), when that count produced them
+        const SortedAux aux = perm ? SortedAux{nullptr, nullptr, nullptr, const_cast<uint2 *>(masks)} : sorted_aux(ctx, N);
         if (rec) {
             const CullBox cb{(float)tile_size, pixel_offset};
             if (perm)
@@ -616,7 +619,7 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     GS_HIP(hipGetLastError());
 
     return bin_emit_sort(ctx, N, rect, depths, grid, rec, tile_size, pixel_offset, perm, (const uint32_t *)ctx->offsets.p, D,
-                         keys, vals, ranges);
+                         keys, vals, ranges, rec && perm ? (const uint2 *)ctx->sorted_aux.p : nullptr);
 }
 
 int cull_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,
@@ -652,7 +655,7 @@ extern "C" int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t
         {&ctx->bounds, batch_views ? (size_t)GS_BIN_MAX_VIEWS * 256 * sizeof(ulonglong2) + 2 * GS_BIN_MAX_VIEWS * 8 : 0},
         {&ctx->tile_order_buf, blocks16 * 2 * sizeof(int32_t)},
         {&ctx->tile_counts, (size_t)gs_div_up(res_w, tile_size) * gs_div_up(res_h, tile_size) * 4}, {&ctx->loss_partials, 1024 * sizeof(double)},
-        {&ctx->sorted_aux, N_max >= ctx->sorted_count_from ? N * 48 : 0},
+        {&ctx->sorted_aux, N_max >= ctx->sorted_count_from ? N * 56 : N * 8},
         {&ctx->packed, array_api ? N * 64 : 0}, {&ctx->grad_rows, array_api ? N * 64 : 0}};
     for (auto &w : want)
         if (w.bytes)

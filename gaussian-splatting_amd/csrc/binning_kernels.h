@@ -175,9 +175,10 @@ struct CullBox {
     float tile, off;   // tile size in pixels, pixel_offset
 };
 
-__device__ __forceinline__ bool pair_may_contribute(const float4 geo, const float4 con, int tx, int ty, CullBox cb) {
+__device__ __forceinline__ bool pair_may_contribute(const float4 geo, const float4 con, const float2 halves, int tx, int ty,
+                                                    CullBox cb) {
     const float xlo = (float)tx * cb.tile - cb.off, ylo = (float)ty * cb.tile - cb.off;
-    return gs_box_may_contribute(geo, con, xlo, xlo + cb.tile - 1.0f, ylo, ylo + cb.tile - 1.0f);
+    return gs_box_may_contribute(geo, con, xlo, xlo + cb.tile - 1.0f, ylo, ylo + cb.tile - 1.0f, halves);
 }
 
 // One wave per 64 consecutive gaussians; the wave walks the concatenation of their rects 64 pairs at a
@@ -191,10 +192,17 @@ __device__ __forceinline__ bool pair_may_contribute(const float4 geo, const floa
 // rect / depth / record of perm[i]).  There the depth sort runs FIRST and the count walks the gaussians in depth
 // order: it gathers once, leaves counts[] in that order (the scans stream it) and a 48-byte summary per gaussian
 // (clipped rect, id, the two record quarters of the box test) that the emit pass streams instead of gathering again.
+//
+// Box test once (mask != nullptr, any mode): a gaussian whose clipped rect has at most 64 tiles -- nearly all of them --
+// gets the outcome of its tests as a 64-bit mask from the count pass (bit = position in the rect), and the emit pass
+// reads the bit instead of evaluating the quadratic again (and does not load the record quarters of such a gaussian);
+// larger rects are tested in both passes as before.  mask[] is indexed like counts[] (gaussian id in modes 0 / 1,
+// depth-order position in modes 2 / 3).
 struct SortedAux {
     int4 *info;      // x0 | w << 16, y0, h, gaussian
     float4 *geo;     // record quarter 0 (culled lists only)
     float4 *con;     // record quarter 1
+    uint2 *mask;     // test outcomes of rects of <= 64 tiles
 };
 
 enum { PAIRS_COUNT = 0, PAIRS_EMIT = 1, PAIRS_COUNT_SORTED = 2, PAIRS_EMIT_AUX = 3 };
@@ -211,20 +219,26 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
     __shared__ uint32_t s_first[4][64];  // exclusive prefix of rect sizes within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
     __shared__ float4 s_geo[4][64], s_con[4][64];
+    __shared__ float2 s_half[4][64];     // the two divisions of the box test, once per gaussian
     __shared__ uint32_t s_pass[4][64];
     __shared__ uint32_t s_mark[4][64];
+    __shared__ uint32_t s_cnt[4][64], s_mlo[4][64], s_mhi[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = (bid * 4 + wave) * 64;
     const int i = i0 + lane;
+    const bool use_mask = aux.mask != nullptr;
     uint32_t cnt = 0;
     int x0 = 0, y0 = 0, h = 1, g = 0;
     float4 geo = make_float4(0.f, 0.f, 0.f, 0.f), con = geo;
+    uint2 bits = make_uint2(0u, 0u);
     if (MODE == PAIRS_EMIT_AUX) {
         if (i < N) {
             const int4 inf = aux.info[i];
             x0 = inf.x & 0xFFFF; y0 = inf.y; h = inf.z; g = inf.w;
             cnt = (uint32_t)(inf.x >> 16) * (uint32_t)h;
-            if (cnt) {
+            if (cnt && use_mask && cnt <= 64u) {
+                bits = aux.mask[i];
+            } else if (cnt) {
                 geo = aux.geo[i];
                 con = aux.con[i];
             }
@@ -234,7 +248,9 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
         // perm may be the caller's array (gs_bin_fill_prepared): an id that is not a gaussian owns no pair
         if ((uint32_t)g < (uint32_t)N) cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
         else g = 0;
-        if (cnt) {
+        if (cnt && MODE == PAIRS_EMIT && use_mask && cnt <= 64u) {
+            bits = aux.mask[g];
+        } else if (cnt) {
             geo = rec[(size_t)g * 4];
             con = rec[(size_t)g * 4 + 1];
         }
@@ -251,7 +267,11 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
     s_info[wave][lane] = make_int4(x0, y0, h, g);
     s_geo[wave][lane] = geo;
     s_con[wave][lane] = con;
+    s_half[wave][lane] = gs_box_halves(con);
     s_pass[wave][lane] = 0u;
+    s_cnt[wave][lane] = cnt;
+    s_mlo[wave][lane] = bits.x;
+    s_mhi[wave][lane] = bits.y;
     const uint32_t wave_total = __shfl(inc, 63, 64);   // 0 when the whole wave is past N
     uint32_t out = (CULL_EMIT && i0 < N) ? offsets[i0] : 0u;
     uint32_t carry = 0;
@@ -265,7 +285,14 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
             const uint32_t local = sidx - s_first[wave][lo];
             tx = inf.x + (int)(local / (uint32_t)inf.z);
             ty = inf.y + (int)(local % (uint32_t)inf.z);
-            pass = pair_may_contribute(s_geo[wave][lo], s_con[wave][lo], tx, ty, cb);
+            if (CULL_EMIT && use_mask && s_cnt[wave][lo] <= 64u)      // decided by the count pass
+                pass = (((local < 32u ? s_mlo[wave][lo] : s_mhi[wave][lo]) >> (local & 31u)) & 1u) != 0u;
+            else
+                pass = pair_may_contribute(s_geo[wave][lo], s_con[wave][lo], s_half[wave][lo], tx, ty, cb);
+            if (!CULL_EMIT && pass) {
+                if (use_mask && s_cnt[wave][lo] <= 64u) atomicOr(local < 32u ? &s_mlo[wave][lo] : &s_mhi[wave][lo], 1u << (local & 31u));
+                else atomicAdd(&s_pass[wave][lo], 1u);
+            }
         }
         if (CULL_EMIT) {
             const unsigned long long m = __ballot(pass);
@@ -275,13 +302,16 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
                     pairs[pos] = make_uint2((uint32_t)(tx * grid.tiles_y + ty), (uint32_t)s_info[wave][lo].w);
             }
             out += (uint32_t)__popcll(m);
-        } else if (pass) {
-            atomicAdd(&s_pass[wave][lo], 1u);
         }
     }
     if (!CULL_EMIT) {
         __syncthreads();
-        if (i < N) counts[i] = s_pass[wave][lane];
+        if (i < N) {
+            const bool small = use_mask && cnt <= 64u;
+            const uint32_t lo32 = s_mlo[wave][lane], hi32 = s_mhi[wave][lane];
+            counts[i] = small ? (uint32_t)(__popc(lo32) + __popc(hi32)) : s_pass[wave][lane];
+            if (use_mask) aux.mask[i] = make_uint2(lo32, hi32);      // (mode 0: i is the gaussian id)
+        }
     }
 }
 

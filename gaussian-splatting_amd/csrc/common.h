@@ -86,7 +86,8 @@ struct gs_ctx {
     // scan and emit kernels stream depth-ordered arrays instead of gathering (binning_kernels.h, SortedAux)
     int32_t sorted_count_from = 2 << 20;
     bool count_sorted = false;        // the pending / last count of this ctx ran in that form
-    gs_buf sorted_aux;                // 48 B per gaussian: clipped rect + id, two record quarters, in depth order
+    gs_buf sorted_aux;                // 56 B per gaussian in depth order: clipped rect + id, two record quarters, test mask
+                                      // (the unsorted culled count keeps only its 8-byte masks here, by gaussian id)
     int32_t bin_N = -1;
     int64_t bin_D = -1;
     uint32_t bin_max_depth = 0;
@@ -151,8 +152,12 @@ int gs_pack_records(gs_ctx *ctx, int32_t N, const float *centers, const float *c
 // max over the pixel box [xlo,xhi]x[ylo,yhi] of power2 >= tau ?  u = cx - x in [ulo,uhi], v likewise.
 // Q = alpha u^2 + beta u v + gamma v^2 is convex; outside the origin its box minimum lies on one
 // of the four edges.  Conics that are not positive definite, NaNs included, are kept undecided.
+// inv2g = 0.5 / gamma and inv2a = 0.5 / alpha depend on the gaussian only: callers that test one gaussian against many
+// boxes compute them once (gs_box_halves) and pass them in; same operations, same result.
+__device__ __forceinline__ float2 gs_box_halves(const float4 con) { return make_float2(0.5f / -con.z, 0.5f / -con.x); }
+
 __device__ __forceinline__ bool gs_box_may_contribute(const float4 geo, const float4 con, float xlo, float xhi,
-                                                      float ylo, float yhi) {
+                                                      float ylo, float yhi, const float2 halves) {
     const float ulo = geo.x - xhi, uhi = geo.x - xlo, vlo = geo.y - yhi, vhi = geo.y - ylo;
     const float al = -con.x, be = -con.y, ga = -con.z;
     if (geo.w >= 1e29f) return false;        // opacity <= 0 or NaN (tau = 1e30): alpha never reaches 1/255
@@ -162,7 +167,7 @@ __device__ __forceinline__ bool gs_box_may_contribute(const float4 geo, const fl
     if (ulo <= 0.0f && uhi >= 0.0f && vlo <= 0.0f && vhi >= 0.0f) {
         qmin = 0.0f;
     } else {
-        const float inv2g = 0.5f / ga, inv2a = 0.5f / al;
+        const float inv2g = halves.x, inv2a = halves.y;
         float v = fminf(fmaxf(-be * ulo * inv2g, vlo), vhi);
         float q0 = al * ulo * ulo + (be * ulo + ga * v) * v;
         v = fminf(fmaxf(-be * uhi * inv2g, vlo), vhi);
@@ -175,4 +180,8 @@ __device__ __forceinline__ bool gs_box_may_contribute(const float4 geo, const fl
     }
     // relative slack on qmin covers the rounding of the edge evaluation itself
     return !(-qmin * 0.999f + 1e-4f < geo.w);
+}
+__device__ __forceinline__ bool gs_box_may_contribute(const float4 geo, const float4 con, float xlo, float xhi,
+                                                      float ylo, float yhi) {
+    return gs_box_may_contribute(geo, con, xlo, xhi, ylo, yhi, gs_box_halves(con));
 }
