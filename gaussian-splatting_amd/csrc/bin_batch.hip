@@ -359,7 +359,7 @@ extern "C" int gs_bin_culled_batch(gs_ctx *ctx, int32_t N, int32_t n_views, cons
         return GS_OK;
     }
 
-    const CullBox cb{(float)tile_size, pixel_offset};
+    const CullBox cb{(float)tile_size, pixel_offset, ctx->cull_shrink ? 1 : 0};
     PairsArgs pa{};
     for (int v = 0; v < nv; v++) {
         pa.rect[v] = reinterpret_cast<const int4 *>(views[v].tiles_touched);
@@ -531,7 +531,7 @@ extern "C" int gs_bin_prepare_begin(gs_ctx *ctx, int32_t N, int32_t n_views, con
     if ((rc = prepare_workspace(ctx, N, n_views, n4, bs4, tab4, scan_blocks))) { ctx->prepare_pending_views = 0; return rc; }
     if (!ctx->bounds_event) GS_HIP(hipEventCreateWithFlags(&ctx->bounds_event, hipEventDisableTiming));
     const Grid grid{gs_div_up(res_w, tile_size), gs_div_up(res_h, tile_size)};
-    const CullBox cb{(float)tile_size, pixel_offset};
+    const CullBox cb{(float)tile_size, pixel_offset, ctx->cull_shrink ? 1 : 0};
     PairsArgs pa{};
     for (int v = 0; v < n_views; v++) {
         pa.rect[v] = reinterpret_cast<const int4 *>(views[v].tiles_touched);

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void count_sorted_kernel(int N, const
                                                                     const int4 *__restrict__ rect,
                                                                     const int32_t *__restrict__ depth, Grid grid,
                                                                     uint32_t *__restrict__ counts, int4 *__restrict__ info,
-                                                                    ulonglong2 *__restrict__ partials) {
+                                                                    ulonglong2 *__restrict__ partials,
+                                                                    const uint32_t *__restrict__ depth_sorted) {
     __shared__ uint32_t s_max[SCAN_THREADS / 64];
     __shared__ unsigned long long s_sum[SCAN_THREADS / 64];
     unsigned long long c = 0;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void count_sorted_kernel(int N, const
     for (int i = blockIdx.x * SCAN_THREADS + threadIdx.x; i < N; i += COUNT_BLOCKS * SCAN_THREADS) {
         const int g = perm[i];
         int x0, y0, h;
-        const int d = depth[g];
+        const int d = depth_sorted ? (int)depth_sorted[i] : depth[g];
         const uint32_t cg = tile_count(rect[g], d, grid, x0, y0, h);
         counts[i] = cg;
         info[i] = make_int4(x0 | (int)((cg ? cg / (uint32_t)h : 0u) << 16), y0, h, g);
@@ -369,7 +370,8 @@ int gs_radix_sort_pairs(gs_ctx *ctx, uint32_t n, const uint32_t *keys_in, const 
 namespace {
 
 // K4a: gaussians into (u32(depth), id) order, the low `depth_bits` bits of the key (the bits max(depth) occupies)
-int bin_depth_sort(gs_ctx *ctx, int32_t N, const int32_t *depths, int depth_bits, const int32_t **perm_out) {
+int bin_depth_sort(gs_ctx *ctx, int32_t N, const int32_t *depths, int depth_bits, const int32_t **perm_out,
+                   const uint32_t **keys_out = nullptr) {
     int rc;
     const size_t n4 = ((size_t)N * 4 + 255) & ~(size_t)255;
     if ((rc = gs_buf_reserve(ctx, &ctx->depth_sort, 4 * n4))) return rc;
@@ -383,19 +385,21 @@ int bin_depth_sort(gs_ctx *ctx, int32_t N, const int32_t *depths, int depth_bits
     for (int p = 0; p < depth_passes; p++) {
         const bool last = p == depth_passes - 1;
         const int nbits = last ? (depth_bits - 8 * p > 0 ? depth_bits - 8 * p : 1) : 8;
-        if ((rc = radix_pass(ctx, (uint32_t)N, soa_io(kin, vin, last ? nullptr : dk[p & 1], dv[p & 1]), RADIX_SOA, 8 * p, nbits)))
+        if ((rc = radix_pass(ctx, (uint32_t)N, soa_io(kin, vin, last && !keys_out ? nullptr : dk[p & 1], dv[p & 1]), RADIX_SOA, 8 * p,
+                             nbits)))
             return rc;
         kin = dk[p & 1];
         vin = dv[p & 1];
     }
     *perm_out = vin;
+    if (keys_out) *keys_out = kin;      // the keys in sorted order (the last pass wrote them too)
     return GS_OK;
 }
 
 SortedAux sorted_aux(gs_ctx *ctx, int32_t N) {
     char *base = (char *)ctx->sorted_aux.p;
     const size_t n16 = (size_t)N * 16;
-    return SortedAux{(int4 *)base, (float4 *)(base + n16), (float4 *)(base + 2 * n16), (uint2 *)(base + 3 * n16)};
+    return SortedAux{(int4 *)base, (float4 *)(base + n16), (float4 *)(base + 2 * n16), (uint2 *)(base + 3 * n16), nullptr};
 }
 
 // rec == nullptr: the reference's rect semantics; otherwise pairs are culled with the box test.
@@ -426,14 +430,18 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
     ctx->count_sorted = N >= ctx->sorted_count_from;
     if (ctx->count_sorted) {
         const int32_t *perm = nullptr;
-        if ((rc = bin_depth_sort(ctx, N, depths, 32, &perm))) return rc;
+        const uint32_t *depth_sorted = nullptr;
+        if ((rc = bin_depth_sort(ctx, N, depths, 32, &perm, &depth_sorted))) return rc;
         if ((rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 56))) return rc;
-        const SortedAux aux = sorted_aux(ctx, N);
+        SortedAux aux = sorted_aux(ctx, N);
+        aux.depth_sorted = depth_sorted;
+        // records written by K1 (gs_ctx_use_records) carry the tile rect in their fourth quarter: one gathered line
+        const int4 *rect_src = rec && rec == ctx->ext_records ? nullptr : reinterpret_cast<const int4 *>(tiles_touched);
         gs_prof_scope prof_(ctx, GS_K_COUNT);
         if (rec) {
-            const CullBox cb{(float)tile_size, pixel_offset};
+            const CullBox cb{(float)tile_size, pixel_offset, ctx->cull_shrink ? 1 : 0};
             hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_COUNT_SORTED>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
-                               perm, reinterpret_cast<const int4 *>(tiles_touched), depths, grid, rec, cb,
+                               perm, rect_src, depths, grid, rec, cb,
                                (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr, aux);
             // (D only: the depth read beside a count belongs to another gaussian here, and max(depth) is not needed)
             hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
@@ -441,20 +449,20 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
         } else {
             hipLaunchKernelGGL(count_sorted_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N, perm,
                                reinterpret_cast<const int4 *>(tiles_touched), depths, grid, (uint32_t *)ctx->counts.p,
-                               aux.info, partials);
+                               aux.info, partials, depth_sorted);
         }
         hipLaunchKernelGGL(count_total_kernel, dim3(1), dim3(COUNT_BLOCKS), 0, ctx->stream,
                            (const ulonglong2 *)partials, (unsigned long long *)ctx->total.p);
     } else {
-        if (rec && (rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 8))) return rc;
+        if (rec && (rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 24))) return rc;
         gs_prof_scope prof_(ctx, GS_K_COUNT);
         if (rec) {
-            const CullBox cb{(float)tile_size, pixel_offset};
-            // (the buffer holds only the per-gaussian test masks in this form)
+            const CullBox cb{(float)tile_size, pixel_offset, ctx->cull_shrink ? 1 : 0};
+            // (in this form the buffer holds the walked rect and the test mask of every gaussian, by gaussian id)
             hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_COUNT>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                                (const int32_t *)nullptr, reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
                                rec, cb, (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr,
-                               SortedAux{nullptr, nullptr, nullptr, (uint2 *)ctx->sorted_aux.p});
+                               SortedAux{(int4 *)ctx->sorted_aux.p, nullptr, nullptr, (uint2 *)((char *)ctx->sorted_aux.p + (size_t)N * 16), nullptr});
             hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
                                (const uint32_t *)ctx->counts.p, depths, partials);
         } else {
@@ -502,7 +510,7 @@ int bin_count_end(gs_ctx *ctx, int64_t *D_host) {
 // perm == nullptr: the gaussians' summaries in depth order are in ctx->sorted_aux (bin_count_begin's sorted form)
 int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depths, Grid grid, const float4 *rec,
                   int32_t tile_size, float pixel_offset, const int32_t *perm, const uint32_t *offsets, int64_t D,
-                  uint64_t *keys, int32_t *vals, int32_t *ranges, const uint2 *masks = nullptr) {
+                  uint64_t *keys, int32_t *vals, int32_t *ranges, bool own_count = false) {
     int rc;
     const int tiles = grid.tiles_x * grid.tiles_y;
     const size_t d4 = ((size_t)D * 4 + 255) & ~(size_t)255;
@@ -527,10 +535,13 @@ int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depth
     }
     {
         gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
-        // masks: the test outcomes of this ctx's own culled count (gaussian order), when that count produced them
-        const SortedAux aux = perm ? SortedAux{nullptr, nullptr, nullptr, const_cast<uint2 *>(masks)} : sorted_aux(ctx, N);
+        // own_count: walked rects and test masks of this ctx's own unsorted culled count (by gaussian id)
+        const SortedAux aux = !perm ? sorted_aux(ctx, N)
+                              : own_count ? SortedAux{(int4 *)ctx->sorted_aux.p, nullptr, nullptr,
+                                                      (uint2 *)((char *)ctx->sorted_aux.p + (size_t)N * 16), nullptr}
+                                          : SortedAux{};
         if (rec) {
-            const CullBox cb{(float)tile_size, pixel_offset};
+            const CullBox cb{(float)tile_size, pixel_offset, ctx->cull_shrink ? 1 : 0};
             if (perm)
                 hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_EMIT>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm,
                                    rect, depths, grid, rec, cb, (uint32_t *)nullptr, offsets, (uint32_t)D, pp[0], aux);
@@ -619,7 +630,7 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     GS_HIP(hipGetLastError());
 
     return bin_emit_sort(ctx, N, rect, depths, grid, rec, tile_size, pixel_offset, perm, (const uint32_t *)ctx->offsets.p, D,
-                         keys, vals, ranges, rec && perm ? (const uint2 *)ctx->sorted_aux.p : nullptr);
+                         keys, vals, ranges, rec && perm);
 }
 
 int cull_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,
@@ -655,7 +666,7 @@ extern "C" int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t
         {&ctx->bounds, batch_views ? (size_t)GS_BIN_MAX_VIEWS * 256 * sizeof(ulonglong2) + 2 * GS_BIN_MAX_VIEWS * 8 : 0},
         {&ctx->tile_order_buf, blocks16 * 2 * sizeof(int32_t)},
         {&ctx->tile_counts, (size_t)gs_div_up(res_w, tile_size) * gs_div_up(res_h, tile_size) * 4}, {&ctx->loss_partials, 1024 * sizeof(double)},
-        {&ctx->sorted_aux, N_max >= ctx->sorted_count_from ? N * 56 : N * 8},
+        {&ctx->sorted_aux, N_max >= ctx->sorted_count_from ? N * 56 : N * 24},
         {&ctx->packed, array_api ? N * 64 : 0}, {&ctx->grad_rows, array_api ? N * 64 : 0}};
     for (auto &w : want)
         if (w.bytes)

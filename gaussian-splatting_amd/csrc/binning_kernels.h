@@ -173,7 +173,37 @@ __device__ __forceinline__ void sorted_offsets_body(int bid, int N, const int32_
 // the reference's list with those entries removed (same order); images and gradients are unchanged.
 struct CullBox {
     float tile, off;   // tile size in pixels, pixel_offset
+    int shrink;        // 1: walk only the tiles inside the ellipse's own bounding box (cull_shrink below)
 };
+
+// The rect the count and emit passes walk is the reference's bounding square of 3 sigma of the LARGER axis; the pairs
+// that can pass the box test lie inside the axis-aligned bounding box of the ellipse Q(u, v) <= qmax (qmax from the
+// test's own threshold), which is smaller for elongated or faint gaussians.  Shrinking the walked rect to that box,
+// grown by 0.1 % and one pixel, only skips pairs the exact test rejects (a tile wholly beyond u_max has
+// Q >= u^2 det / gamma > qmax by that margin): the lists do not change, fewer tests run.  Conics that are not
+// positive definite keep their rect (the test keeps every pair of theirs).
+__device__ __forceinline__ void cull_shrink(const float4 geo, const float4 con, CullBox cb, int &x0, int &y0, int &w, int &h) {
+    const float al = -con.x, be = -con.y, ga = -con.z;
+    if (!(al > 0.0f && ga > 0.0f && be * be < 4.0f * al * ga)) return;
+    if (geo.w >= 1e29f) { w = 0; h = 0; return; }            // the test rejects every pair
+    const float qmax = (1e-4f - geo.w) / 0.999f;             // the test passes iff qmin * 0.999 <= 1e-4 - tau
+    if (qmax < 0.0f) { w = 0; h = 0; return; }               // qmin >= 0: nothing passes
+    const float det = al * ga - 0.25f * be * be;
+    if (!(det > 0.0f) || !(qmax < 1e30f)) return;
+    const float um = sqrtf(qmax * ga / det) * 1.001f + 1.0f, vm = sqrtf(qmax * al / det) * 1.001f + 1.0f;
+    if (!(um < 1e9f) || !(vm < 1e9f)) return;
+    // tile t covers pixels [t * tile - off, t * tile - off + tile - 1]; it can pass only if that meets [c - m, c + m]
+    const float lim = 1e9f;
+    const float fx0 = fminf(fmaxf((geo.x - um + cb.off - (cb.tile - 1.0f)) / cb.tile, -lim), lim);
+    const float fx1 = fminf(fmaxf((geo.x + um + cb.off) / cb.tile, -lim), lim);
+    const float fy0 = fminf(fmaxf((geo.y - vm + cb.off - (cb.tile - 1.0f)) / cb.tile, -lim), lim);
+    const float fy1 = fminf(fmaxf((geo.y + vm + cb.off) / cb.tile, -lim), lim);
+    if (!(fx0 == fx0) || !(fx1 == fx1) || !(fy0 == fy0) || !(fy1 == fy1)) return;      // NaN centre: keep
+    const int nx0 = max(x0, (int)ceilf(fx0)), nx1 = min(x0 + w - 1, (int)floorf(fx1));
+    const int ny0 = max(y0, (int)ceilf(fy0)), ny1 = min(y0 + h - 1, (int)floorf(fy1));
+    if (nx1 < nx0 || ny1 < ny0) { w = 0; h = 0; return; }
+    x0 = nx0; y0 = ny0; w = nx1 - nx0 + 1; h = ny1 - ny0 + 1;
+}
 
 __device__ __forceinline__ bool pair_may_contribute(const float4 geo, const float4 con, const float2 halves, int tx, int ty,
                                                     CullBox cb) {
@@ -203,6 +233,7 @@ struct SortedAux {
     float4 *geo;     // record quarter 0 (culled lists only)
     float4 *con;     // record quarter 1
     uint2 *mask;     // test outcomes of rects of <= 64 tiles
+    const uint32_t *depth_sorted;   // mode 2: the depth keys in depth order (the sort's own output) -- no gather
 };
 
 enum { PAIRS_COUNT = 0, PAIRS_EMIT = 1, PAIRS_COUNT_SORTED = 2, PAIRS_EMIT_AUX = 3 };
@@ -243,20 +274,55 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
                 con = aux.con[i];
             }
         }
+    } else if (MODE == PAIRS_EMIT && aux.info != nullptr) {
+        // this ctx's own count pass left the walked rect (and the mask) of every gaussian, by gaussian id: two small
+        // gathers instead of rect + depth + record
+        if (i < N) {
+            g = perm[i];
+            const int4 inf = aux.info[g];
+            x0 = inf.x & 0xFFFF; y0 = inf.y; h = inf.z;
+            cnt = (uint32_t)(inf.x >> 16) * (uint32_t)h;
+            if (cnt && use_mask && cnt <= 64u) {
+                bits = aux.mask[g];
+            } else if (cnt) {
+                geo = rec[(size_t)g * 4];
+                con = rec[(size_t)g * 4 + 1];
+            }
+        }
     } else if (i < N) {
         g = MODE == PAIRS_COUNT ? i : perm[i];
         // perm may be the caller's array (gs_bin_fill_prepared): an id that is not a gaussian owns no pair
-        if ((uint32_t)g < (uint32_t)N) cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
-        else g = 0;
+        if ((uint32_t)g < (uint32_t)N) {
+            if (MODE == PAIRS_COUNT_SORTED) {
+                // one gathered line per gaussian where K1 wrote the records (their fourth quarter is the tile rect)
+                const float4 rq = rect ? make_float4(0.f, 0.f, 0.f, 0.f) : rec[(size_t)g * 4 + 3];
+                const int4 r = rect ? rect[g] : make_int4(__float_as_int(rq.x), __float_as_int(rq.y), __float_as_int(rq.z),
+                                                          __float_as_int(rq.w));
+                cnt = tile_count(r, aux.depth_sorted ? (int)aux.depth_sorted[i] : depth[g], grid, x0, y0, h);
+            } else {
+                cnt = tile_count(rect[g], depth[g], grid, x0, y0, h);
+            }
+        } else {
+            g = 0;
+        }
+        if (cnt && cb.shrink) {        // (the record is read first: its line is needed below in any case)
+            const float4 g0 = rec[(size_t)g * 4], c0 = rec[(size_t)g * 4 + 1];
+            int w = (int)(cnt / (uint32_t)h);
+            cull_shrink(g0, c0, cb, x0, y0, w, h);
+            cnt = (uint32_t)w * (uint32_t)h;
+            if (cnt == 0u) h = 1;
+        }
         if (cnt && MODE == PAIRS_EMIT && use_mask && cnt <= 64u) {
             bits = aux.mask[g];
         } else if (cnt) {
             geo = rec[(size_t)g * 4];
             con = rec[(size_t)g * 4 + 1];
         }
-        if (MODE == PAIRS_COUNT_SORTED) {
+        if (MODE == PAIRS_COUNT_SORTED || (MODE == PAIRS_COUNT && aux.info != nullptr)) {
             const uint32_t w = cnt ? cnt / (uint32_t)h : 0u;      // cnt = w * h; no pair: w = 0
             aux.info[i] = make_int4(x0 | (int)(w << 16), y0, h, g);
+        }
+        if (MODE == PAIRS_COUNT_SORTED) {
             aux.geo[i] = geo;
             aux.con[i] = con;
         }

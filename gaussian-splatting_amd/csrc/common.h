@@ -85,9 +85,10 @@ struct gs_ctx {
     // option sorted_count_from: from this many gaussians on the depth sort runs before the tile count and the count,
     // scan and emit kernels stream depth-ordered arrays instead of gathering (binning_kernels.h, SortedAux)
     int32_t sorted_count_from = 2 << 20;
+    bool cull_shrink = true;          // option cull_shrink_rect: culled count / emit walk the ellipse's own bounding box
     bool count_sorted = false;        // the pending / last count of this ctx ran in that form
     gs_buf sorted_aux;                // 56 B per gaussian in depth order: clipped rect + id, two record quarters, test mask
-                                      // (the unsorted culled count keeps only its 8-byte masks here, by gaussian id)
+                                      // (the unsorted culled count keeps walked rect + test mask here, 24 B by gaussian id)
     int32_t bin_N = -1;
     int64_t bin_D = -1;
     uint32_t bin_max_depth = 0;

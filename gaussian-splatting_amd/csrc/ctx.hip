@@ -133,6 +133,11 @@ extern "C" int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value) {
         ctx->tile_hist = value != 0;
         return GS_OK;
     }
+    if (strcmp(name, "cull_shrink_rect") == 0) {
+        GS_REQUIRE(value == 0 || value == 1, "cull_shrink_rect must be 0 or 1 (got %d)", value);
+        ctx->cull_shrink = value != 0;
+        return GS_OK;
+    }
     if (strcmp(name, "sorted_count_from") == 0) {   // gaussians from which the count runs in depth order (0: always)
         GS_REQUIRE(value >= 0, "sorted_count_from must be >= 0 (got %d)", value);
         ctx->sorted_count_from = value;

@@ -327,9 +327,12 @@ __global__ __launch_bounds__(256) GS_K1_OCC void preprocess_batch_kernel(int N, 
             __shared__ float4 s_rec[4][4][68];
             const int lane = threadIdx.x & 63;
             float4 (*st)[68] = s_rec[threadIdx.x >> 6];
-            const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // fourth quarter: the tile rect again, as bits (the culled tile count of large scenes gathers the record's
+            // line anyway and finds the rect in it instead of in a second gathered line)
+            const float4 rq = make_float4(__int_as_float(o.rect[0]), __int_as_float(o.rect[1]), __int_as_float(o.rect[2]),
+                                            __int_as_float(o.rect[3]));
             if (i - lane + 64 <= N) {
-                st[0][lane] = geo; st[1][lane] = con; st[2][lane] = rgb; st[3][lane] = zero;
+                st[0][lane] = geo; st[1][lane] = con; st[2][lane] = rgb; st[3][lane] = rq;
                 float4 *dst = w.records + (size_t)(i - lane) * 4;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) GS_K1_OCC void preprocess_batch_kernel(int N, 
                 }
             } else {                                   // the last, partial wave
                 float4 *r = w.records + (size_t)i * 4;
-                r[0] = geo; r[1] = con; r[2] = rgb; r[3] = zero;
+                r[0] = geo; r[1] = con; r[2] = rgb; r[3] = rq;
             }
         } else {
             store_view(i, b.out[v], o);

@@ -88,7 +88,10 @@ int gs_ctx_reserve(gs_ctx *ctx, int32_t N_max, int64_t D_max, int32_t res_w, int
  * that order, so that the scan and emit kernels of gs_bin_fill* stream depth-ordered arrays (48 bytes of workspace
  * per gaussian) instead of gathering rect / depth / record per gaussian again -- once those arrays outgrow the caches a
  * gather costs a 128-byte line per item.  Default 2 097 152 (also GSPLAT_SORTED_COUNT_FROM); 0 = always.  Same lists
- * bit for bit. */
+ * bit for bit.
+ * "cull_shrink_rect": 1 (default) = the culled count / emit passes walk the tiles inside the axis-aligned bounding box
+ * of the gaussian's own ellipse at its alpha threshold (grown by 0.1 % and a pixel) instead of the whole reference rect;
+ * it only skips pairs the exact box test rejects, so the lists are the same with 0. */
 int gs_ctx_set_option(gs_ctx *ctx, const char *name, int32_t value);
 /* Per-kernel timing with HIP events on the ctx stream (no reference counterpart; the reference
  * only prints perf_counter deltas per stage, train.py:29-60).  While enabled every kernel launch
@@ -130,8 +133,10 @@ int gs_preprocess_batch(gs_ctx *ctx, int32_t N, const float *means, const float 
 
 /* Record-writing form of gs_preprocess_batch (no counterpart in the reference): instead of centers /
  * colors / conics each view receives records[N][16] floats, the 64-byte per-gaussian records the
- * blend and culled-binning kernels read (centre, opacity, alpha threshold, log2-scaled conic, colour),
- * built from `opacities` (activated, [N]).  gs_ctx_use_records(ctx, N, records) then makes the
+ * blend and culled-binning kernels read (centre, opacity, alpha threshold, log2-scaled conic, colour; the last
+ * 16 bytes repeat the tile rect as four int32, which the culled tile count of large scenes reads from there),
+ * built from `opacities` (activated, [N]).  Records handed to gs_ctx_use_records must have been written by this
+ * call.  gs_ctx_use_records(ctx, N, records) then makes the
  * culled-binning and blend calls on that ctx take their per-gaussian inputs from `records` and
  * ignore their centers / colors / opacities / conics arguments (which may be NULL), so no pack pass
  * runs per view; gs_ctx_use_records(ctx, 0, NULL) returns to the arrays.  The records must stay

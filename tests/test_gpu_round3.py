@@ -367,9 +367,20 @@ def test_sorted_count_form_gives_the_same_lists(gpu_ctx):
         got = run()
     finally:
         gpu_ctx.set_option("sorted_count_from", 2 << 20)
-    assert len(ref) == len(got)
-    for k, (a, b) in enumerate(zip(ref, got)):
-        assert a[0] == b[0], k
-        for x, y in zip(a[1:], b[1:]):
-            assert (x is None and y is None) or np.array_equal(x, y), k
+    # the culled passes walk the ellipse's own bounding box instead of the whole rect (cull_shrink_rect, default on): it
+    # only skips pairs the exact test rejects, so the lists are the same without it, in either count form
+    gpu_ctx.set_option("cull_shrink_rect", 0)
+    try:
+        plain = run()
+        gpu_ctx.set_option("sorted_count_from", 0)
+        plain_sorted = run()
+    finally:
+        gpu_ctx.set_option("cull_shrink_rect", 1)
+        gpu_ctx.set_option("sorted_count_from", 2 << 20)
+    for other in (got, plain, plain_sorted):
+        assert len(ref) == len(other)
+        for k, (a, b) in enumerate(zip(ref, other)):
+            assert a[0] == b[0], k
+            for x, y in zip(a[1:], b[1:]):
+                assert (x is None and y is None) or np.array_equal(x, y), k
     assert sum(a[0] for a in ref) > 100_000
