@@ -17,8 +17,12 @@ SHORT = [("blend_bwd_quad", "blend_backward"), ("blend_fwd_quad", "blend_forward
          ("radix_hist_kernel<256, (bool)1>", "tile_hist2"), ("radix_hist_kernel<512, (bool)1>", "tile_hist2"),
          ("radix_hist", "depth_hist"), ("ranges_from_counts", "bin_ranges"),
          ("radix_scan", "radix_scan"), ("duplicate_kernel", "bin_duplicate"), ("pack_kernel", "blend_pack"),
-         ("culled_pairs_kernel<false>", "bin_count_culled"), ("culled_pairs_kernel<true>", "bin_duplicate_culled"),
-         ("culled_pairs_kernel<(bool)0>", "bin_count_culled"), ("culled_pairs_kernel<(bool)1>", "bin_duplicate_culled"),
+         # modes 0 / 2: count (by gaussian id / in depth order), 1 / 3: emit (gathering / from the depth-ordered summaries)
+         ("culled_pairs_kernel<0>", "bin_count_culled"), ("culled_pairs_kernel<2>", "bin_count_culled"),
+         ("culled_pairs_kernel<1>", "bin_duplicate_culled"), ("culled_pairs_kernel<3>", "bin_duplicate_culled"),
+         ("culled_pairs_kernel<(int)0>", "bin_count_culled"), ("culled_pairs_kernel<(int)2>", "bin_count_culled"),
+         ("culled_pairs_kernel<(int)1>", "bin_duplicate_culled"), ("culled_pairs_kernel<(int)3>", "bin_duplicate_culled"),
+         ("count_sorted_kernel", "bin_count"),
          ("count_sum_kernel", "bin_count_sum"), ("count_kernel", "bin_count"), ("ranges_kernel", "bin_ranges"), ("sorted_offsets", "bin_offsets"),
          ("sorted_block_sums", "bin_block_sums")]
 
