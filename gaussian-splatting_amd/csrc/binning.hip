@@ -39,7 +39,7 @@ constexpr int TILE_HIST_MAX = 32768;     // tile ids whose counters fit one work
 __global__ __launch_bounds__(SCAN_THREADS) void count_kernel(int N, const int4 *__restrict__ rect,
                                                              const int32_t *__restrict__ depth, Grid grid,
                                                              uint32_t *__restrict__ counts,
-                                                             ulonglong2 *__restrict__ partials) {
+                                                             ulonglong2 *__restrict__ partials, int4 *__restrict__ info) {
     __shared__ uint32_t s_max[SCAN_THREADS / 64];
     __shared__ unsigned long long s_sum[SCAN_THREADS / 64];
     unsigned long long c = 0;
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void count_kernel(int N, const int4 *
         const int d = depth[g];
         const uint32_t cg = tile_count(rect[g], d, grid, x0, y0, h);
         counts[g] = cg;
+        // the clipped rect (empty when the depth key filters the gaussian out): K3 gathers this one item per gaussian
+        // instead of rect and depth
+        if (info) info[g] = make_int4(x0 | (int)((cg ? cg / (uint32_t)h : 0u) << 16), y0, h, g);
         c += cg;
         if (cg) md = max(md, (uint32_t)d);
     }
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
                                                         const int4 *__restrict__ rect,
                                                         const int32_t *__restrict__ depth, Grid grid,
                                                         const uint32_t *__restrict__ offsets, uint32_t D,
-                                                        uint2 *__restrict__ pairs, const int4 *__restrict__ info) {
+                                                        uint2 *__restrict__ pairs, const int4 *__restrict__ info,
+                                                        int info_by_id) {
     __shared__ uint32_t s_first[4][64];  // exclusive prefix of counts within the wave
     __shared__ int4 s_info[4][64];       // x0, y0, h, gaussian
     __shared__ uint32_t s_mark[4][64];
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int N, const int32_t *__
     const int i = i0 + lane;
     uint32_t cnt = 0;
     int x0 = 0, y0 = 0, h = 1, g = 0;
-    if (i < N && info) {             // large scenes: the clipped rects in depth order, left by count_sorted_kernel
-        const int4 inf = info[i];
+    if (i < N && info) {             // the clipped rects left by the count: in depth order (large scenes) or by id
+        const int4 inf = info[info_by_id ? perm[i] : i];
         x0 = inf.x & 0xFFFF; y0 = inf.y; h = inf.z; g = inf.w;
         cnt = (uint32_t)(inf.x >> 16) * (uint32_t)h;
     } else if (i < N) {
@@ -203,16 +207,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void count_sum_kernel(int N, const ui
 // ------------------------------------------------------------- per-view launches of the shared kernel bodies
 __global__ __launch_bounds__(SCAN_THREADS) void sorted_block_sums_kernel(int N, const int32_t *__restrict__ perm,
                                                                          const uint32_t *__restrict__ counts,
-                                                                         uint32_t *__restrict__ block_sums) {
-    sorted_block_sums_body(blockIdx.x, N, perm, counts, block_sums);
+                                                                         uint32_t *__restrict__ block_sums,
+                                                                         uint32_t *__restrict__ counts_sorted) {
+    sorted_block_sums_body(blockIdx.x, N, perm, counts, block_sums, counts_sorted);
 }
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(int nblocks, uint32_t *__restrict__ block_sums) {
     scan_blocks_body(0, nblocks, block_sums, nullptr);
 }
 __global__ __launch_bounds__(SCAN_THREADS) void sorted_offsets_kernel(int N, const int32_t *__restrict__ perm,
-                                                                      const uint32_t *__restrict__ counts,
+                                                                      const uint32_t *counts,
                                                                       const uint32_t *__restrict__ block_offsets,
-                                                                      uint32_t *__restrict__ offsets) {
+                                                                      uint32_t *offsets) {
     sorted_offsets_body(blockIdx.x, N, perm, counts, block_offsets, offsets);
 }
 template <int MODE>
@@ -454,7 +459,7 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
         hipLaunchKernelGGL(count_total_kernel, dim3(1), dim3(COUNT_BLOCKS), 0, ctx->stream,
                            (const ulonglong2 *)partials, (unsigned long long *)ctx->total.p);
     } else {
-        if (rec && (rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 24))) return rc;
+        if ((rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * (rec ? 24 : 16)))) return rc;
         gs_prof_scope prof_(ctx, GS_K_COUNT);
         if (rec) {
             const CullBox cb{(float)tile_size, pixel_offset, ctx->cull_shrink ? 1 : 0};
@@ -468,7 +473,7 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
         } else {
             hipLaunchKernelGGL(count_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
                                reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
-                               (uint32_t *)ctx->counts.p, partials);
+                               (uint32_t *)ctx->counts.p, partials, (int4 *)ctx->sorted_aux.p);
         }
         hipLaunchKernelGGL(count_total_kernel, dim3(1), dim3(COUNT_BLOCKS), 0, ctx->stream,
                            (const ulonglong2 *)partials, (unsigned long long *)ctx->total.p);
@@ -549,8 +554,9 @@ int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depth
                 hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_EMIT_AUX>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
                                    perm, rect, depths, grid, rec, cb, (uint32_t *)nullptr, offsets, (uint32_t)D, pp[0], aux);
         } else {
+            // (perm with own_count: the clipped rects of this ctx's own count, by gaussian id)
             hipLaunchKernelGGL(duplicate_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N, perm, rect,
-                               depths, grid, offsets, (uint32_t)D, pp[0], (const int4 *)aux.info);
+                               depths, grid, offsets, (uint32_t)D, pp[0], (const int4 *)aux.info, perm ? 1 : 0);
         }
     }
     GS_HIP(hipGetLastError());
@@ -621,16 +627,19 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     uint32_t *bs = (uint32_t *)ctx->block_sums.p;
     {
         gs_prof_scope prof_(ctx, GS_K_SCAN);
+        // the first kernel leaves the counts in depth order in the offsets array, the third turns them into offsets
+        // in place (one gather of counts[perm[i]] instead of two)
+        uint32_t *offs = (uint32_t *)ctx->offsets.p;
         hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N, perm,
-                           counts, bs);
+                           counts, bs, perm ? offs : (uint32_t *)nullptr);
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, nblocks, bs);
-        hipLaunchKernelGGL(sorted_offsets_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N, perm, counts,
-                           (const uint32_t *)bs, (uint32_t *)ctx->offsets.p);
+        hipLaunchKernelGGL(sorted_offsets_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N,
+                           (const int32_t *)nullptr, perm ? (const uint32_t *)offs : counts, (const uint32_t *)bs, offs);
     }
     GS_HIP(hipGetLastError());
 
     return bin_emit_sort(ctx, N, rect, depths, grid, rec, tile_size, pixel_offset, perm, (const uint32_t *)ctx->offsets.p, D,
-                         keys, vals, ranges, rec && perm);
+                         keys, vals, ranges, perm != nullptr);
 }
 
 int cull_records(gs_ctx *ctx, int32_t N, const float *centers, const float *colors, const float *opacities,

@@ -101,14 +101,21 @@ __device__ __forceinline__ uint32_t slot_owner(uint32_t *mark_row, int lane, uin
 }
 
 // K2'a: per-block totals of counts taken in depth order (perm == nullptr: the counts are in that order already)
+// (counts_sorted, if given, receives the counts in depth order, so that K2'c streams them instead of gathering again;
+// it may be K2'c's own output array: that kernel reads an element before the same thread overwrites it)
 __device__ __forceinline__ void sorted_block_sums_body(int bid, int N, const int32_t *__restrict__ perm,
                                                                          const uint32_t *__restrict__ counts,
-                                                                         uint32_t *__restrict__ block_sums) {
+                                                                         uint32_t *__restrict__ block_sums,
+                                                                         uint32_t *__restrict__ counts_sorted = nullptr) {
     const int base = bid * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++)
-        if (base + k < N) sum += counts[perm ? perm[base + k] : base + k];
+        if (base + k < N) {
+            const uint32_t c = counts[perm ? perm[base + k] : base + k];
+            if (counts_sorted) counts_sorted[base + k] = c;
+            sum += c;
+        }
     uint32_t total;
     block_exclusive_scan(sum, &total);
     if (threadIdx.x == 0) block_sums[bid] = total;
@@ -145,9 +152,9 @@ __device__ __forceinline__ void scan_blocks_body(int bid, int nblocks, uint32_t 
 
 // K2'c: exclusive offsets per sorted position
 __device__ __forceinline__ void sorted_offsets_body(int bid, int N, const int32_t *__restrict__ perm,
-                                                                      const uint32_t *__restrict__ counts,
+                                                                      const uint32_t *counts,
                                                                       const uint32_t *__restrict__ block_offsets,
-                                                                      uint32_t *__restrict__ offsets) {
+                                                                      uint32_t *offsets) {
     const int base = bid * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t c[SCAN_ITEMS];
     uint32_t sum = 0;
