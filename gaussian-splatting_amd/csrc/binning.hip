@@ -217,8 +217,8 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(int nblocks, uint32_t
 __global__ __launch_bounds__(SCAN_THREADS) void sorted_offsets_kernel(int N, const int32_t *__restrict__ perm,
                                                                       const uint32_t *counts,
                                                                       const uint32_t *__restrict__ block_offsets,
-                                                                      uint32_t *offsets) {
-    sorted_offsets_body(blockIdx.x, N, perm, counts, block_offsets, offsets);
+                                                                      uint32_t *offsets, int raw_sums) {
+    sorted_offsets_body(blockIdx.x, N, perm, counts, block_offsets, offsets, raw_sums != 0);
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void culled_pairs_kernel(int N, const int32_t *__restrict__ perm,
@@ -632,9 +632,12 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
         uint32_t *offs = (uint32_t *)ctx->offsets.p;
         hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N, perm,
                            counts, bs, perm ? offs : (uint32_t *)nullptr);
-        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, nblocks, bs);
+        // up to 2048 blocks (2 M gaussians) every block of the third kernel sums the totals in front of it itself
+        const bool raw = nblocks <= 2048;
+        if (!raw) hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, nblocks, bs);
         hipLaunchKernelGGL(sorted_offsets_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, N,
-                           (const int32_t *)nullptr, perm ? (const uint32_t *)offs : counts, (const uint32_t *)bs, offs);
+                           (const int32_t *)nullptr, perm ? (const uint32_t *)offs : counts, (const uint32_t *)bs, offs,
+                           raw ? 1 : 0);
     }
     GS_HIP(hipGetLastError());
 

@@ -154,7 +154,7 @@ __device__ __forceinline__ void scan_blocks_body(int bid, int nblocks, uint32_t 
 __device__ __forceinline__ void sorted_offsets_body(int bid, int N, const int32_t *__restrict__ perm,
                                                                       const uint32_t *counts,
                                                                       const uint32_t *__restrict__ block_offsets,
-                                                                      uint32_t *offsets) {
+                                                                      uint32_t *offsets, bool raw_sums = false) {
     const int base = bid * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t c[SCAN_ITEMS];
     uint32_t sum = 0;
@@ -164,7 +164,18 @@ __device__ __forceinline__ void sorted_offsets_body(int bid, int N, const int32_
         sum += c[k];
     }
     uint32_t total;
-    uint32_t run = block_offsets[bid] + block_exclusive_scan(sum, &total);
+    uint32_t run = block_exclusive_scan(sum, &total);
+    if (raw_sums) {
+        // block_offsets holds the per-block TOTALS: this block adds up the ones in front of it itself (a few KiB from
+        // L2) and the one-workgroup scan kernel between K2'a and K2'c is not launched
+        uint32_t before = 0;
+        for (int b = threadIdx.x; b < bid; b += SCAN_THREADS) before += block_offsets[b];
+        uint32_t all;
+        block_exclusive_scan(before, &all);
+        run += all;
+    } else {
+        run += block_offsets[bid];
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         if (base + k < N) offsets[base + k] = run;
