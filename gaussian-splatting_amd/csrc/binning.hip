@@ -243,7 +243,7 @@ __global__ __launch_bounds__(1024) void tile_hist_kernel(uint32_t n, const uint2
     extern __shared__ uint32_t s_tiles_dyn[];
     radix2_hist_tiles_body<1024, ITEMS_PER_1024>(n, pairs, mask, nblocks, table, ntiles, tile_counts, s_tiles_dyn);
 }
-__global__ __launch_bounds__(1024) void ranges_from_counts_kernel(uint32_t ntiles, const uint32_t *__restrict__ tile_counts,
+__global__ __launch_bounds__(1024) void ranges_from_counts_kernel(uint32_t ntiles, uint32_t *__restrict__ tile_counts,
                                                                   int32_t *__restrict__ ranges) {
     ranges_from_counts_body(ntiles, tile_counts, ranges);
 }
@@ -511,7 +511,7 @@ int bin_count_end(gs_ctx *ctx, int64_t *D_host) {
 }
 
 // K3 + K4b + K5 of one view: pairs emitted in depth order (perm) at the scanned offsets, a stable sort by tile id
-// alone, tile ranges.  `ranges` has been zeroed by the caller; D > 0.
+// alone, tile ranges (every tile's entry is written: tiles without pairs get (0, 0)).  D > 0.
 // perm == nullptr: the gaussians' summaries in depth order are in ctx->sorted_aux (bin_count_begin's sorted form)
 int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depths, Grid grid, const float4 *rec,
                   int32_t tile_size, float pixel_offset, const int32_t *perm, const uint32_t *offsets, int64_t D,
@@ -536,7 +536,13 @@ int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depth
     if (hist_ranges) {
         if ((rc = gs_buf_reserve(ctx, &ctx->tile_counts, (size_t)tiles * 4))) return rc;
         tile_counts = (uint32_t *)ctx->tile_counts.p;
-        GS_HIP(hipMemsetAsync(tile_counts, 0, (size_t)tiles * 4, ctx->stream));
+        // ranges_from_counts leaves the counters it read at zero: a memset only for a new buffer or another frame
+        if (ctx->tile_counts_clean != ctx->tile_counts.p || ctx->tile_counts_tiles < tiles)
+            GS_HIP(hipMemsetAsync(tile_counts, 0, ctx->tile_counts.cap, ctx->stream));
+        ctx->tile_counts_clean = nullptr;      // dirty until the ranges kernel below has been enqueued
+    } else {
+        // ranges_kernel only writes the tiles that own pairs (ranges_from_counts writes every tile)
+        GS_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, ctx->stream));
     }
     {
         gs_prof_scope prof_(ctx, GS_K_DUPLICATE);
@@ -579,9 +585,11 @@ int bin_emit_sort(gs_ctx *ctx, int32_t N, const int4 *rect, const int32_t *depth
 
     if (hist_ranges) {
         gs_prof_scope prof_(ctx, GS_K_RANGES);
-        hipLaunchKernelGGL(ranges_from_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, (uint32_t)tiles,
-                           (const uint32_t *)tile_counts, ranges);
+        hipLaunchKernelGGL(ranges_from_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, (uint32_t)tiles, tile_counts,
+                           ranges);
         GS_HIP(hipGetLastError());
+        ctx->tile_counts_clean = ctx->tile_counts.p;
+        ctx->tile_counts_tiles = tiles;
         return GS_OK;
     }
     {
@@ -609,8 +617,10 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     GS_HIP(hipSetDevice(ctx->device));
     const Grid grid{gs_div_up(res_w, tile_size), gs_div_up(res_h, tile_size)};
     const int tiles = grid.tiles_x * grid.tiles_y;
-    GS_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, ctx->stream));
-    if (D == 0) return GS_OK;
+    if (D == 0) {
+        GS_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, ctx->stream));
+        return GS_OK;
+    }
     GS_REQUIRE(vals, "gs_bin_fill: vals is NULL with D=%lld", (long long)D);
     const int4 *rect = reinterpret_cast<const int4 *>(tiles_touched);
     // K4a: gaussians into (u32(depth), id) order; only the bytes max(depth) occupies are sorted.  (Done already, and
@@ -724,8 +734,10 @@ extern "C" int gs_bin_fill_prepared(gs_ctx *ctx, int32_t N, const int32_t *tiles
     ctx->packed_fresh = false;
     GS_HIP(hipSetDevice(ctx->device));
     const Grid grid{gs_div_up(res_w, tile_size), gs_div_up(res_h, tile_size)};
-    GS_HIP(hipMemsetAsync(ranges, 0, (size_t)grid.tiles_x * grid.tiles_y * 8, ctx->stream));
-    if (D == 0 || N == 0) return GS_OK;
+    if (D == 0 || N == 0) {
+        GS_HIP(hipMemsetAsync(ranges, 0, (size_t)grid.tiles_x * grid.tiles_y * 8, ctx->stream));
+        return GS_OK;
+    }
     GS_REQUIRE(vals && perm && offsets, "gs_bin_fill_prepared: NULL vals / perm / offsets with D=%lld", (long long)D);
     return bin_emit_sort(ctx, N, reinterpret_cast<const int4 *>(tiles_touched), depths, grid,
                          reinterpret_cast<const float4 *>(records), tile_size, pixel_offset, perm, offsets, D, keys, vals,

@@ -81,6 +81,8 @@ struct gs_ctx {
     int tile_order_min = 2048, tile_order_max = 16384;   // ... for frames with this many 16x16 blocks
     gs_buf tile_order_buf;            // i32[ntiles] launch order + i32[ntiles] work per tile
     gs_buf tile_counts;               // u32[tiles] pairs per tile (first pass of the tile sort -> K5)
+    const void *tile_counts_clean = nullptr;   // == tile_counts.p while its first tile_counts_tiles counters are zero
+    int tile_counts_tiles = 0;
     bool tile_hist = true;            // option tile_histogram: K5 from that histogram instead of the sorted tile ids
     // option sorted_count_from: from this many gaussians on the depth sort runs before the tile count and the count,
     // scan and emit kernels stream depth-ordered arrays instead of gathering (binning_kernels.h, SortedAux)

@@ -131,7 +131,8 @@ __device__ __forceinline__ void radix2_hist_tiles_body(uint32_t n, const uint2 *
 
 // K5 from the per-tile counts: ranges[t] = [start, start + count) with start = pairs in tiles before t; tiles
 // without pairs keep (0, 0), as the reference's lists have it.  One 1024-thread workgroup.
-__device__ __forceinline__ void ranges_from_counts_body(uint32_t ntiles, const uint32_t *__restrict__ tile_counts,
+// The counters are zeroed again as they are read, ready for the next view's histogram (no memset per view).
+__device__ __forceinline__ void ranges_from_counts_body(uint32_t ntiles, uint32_t *__restrict__ tile_counts,
                                                         int32_t *__restrict__ ranges) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
@@ -144,6 +145,7 @@ __device__ __forceinline__ void ranges_from_counts_body(uint32_t ntiles, const u
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             c[k] = t0 + k < ntiles ? tile_counts[t0 + k] : 0u;
+            if (c[k]) tile_counts[t0 + k] = 0u;
             sum += c[k];
         }
         const uint32_t inc = wave_inclusive_scan(sum);
