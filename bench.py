@@ -113,14 +113,21 @@ def make_scene(N, W, H, log_scale, seed=20240601):
     return g, cam
 
 
-def make_views(gs, cam, n_views):
+def make_views(gs, cam, n_views, group=None, world=1):
     """Small yaw/pitch rotations about the origin: every gaussian stays in front of the near cull
     in every view, so each view carries the same 1M-gaussian workload (the reference takes the 2D
-    centre from world coordinates, quirk Q1; the view changes depth order and covariances)."""
+    centre from world coordinates, quirk Q1; the view changes depth order and covariances).
+    group (weak scaling: the views per rank; view k belongs to rank k % world, shard_views): the pattern of `group`
+    views repeats for every rank with a small
+    offset (0.11 deg yaw, 0.07 deg pitch per rank), so that every rank renders distinct views of the SAME workload --
+    one pattern spread over 8 x 8 views would reach 47 deg of yaw, where gaussians leave through the near plane and
+    others blow up on screen: another workload per rank."""
+    group = n_views if not group else group
     views = []
     for k in range(n_views):
-        yaw = math.radians((k - (n_views - 1) / 2.0) * 1.5)
-        pitch = math.radians(((k * 3) % n_views - (n_views - 1) / 2.0) * 0.6)
+        kk, r = ((k // world) % group, k % world) if group != n_views else (k, 0)
+        yaw = math.radians((kk - (group - 1) / 2.0) * 1.5 + 0.11 * r)
+        pitch = math.radians(((kk * 3) % group - (group - 1) / 2.0) * 0.6 + 0.07 * r)
         cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
         Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
         Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
@@ -185,7 +192,8 @@ def main():
     pipe = gs.SplatPipeline(g, [W, H], opacity_is_logit=True, ctx=ctx, cull_tiles=args.lists == "culled")
     weak = args.views_per_rank > 0
     n_views = 1 if args.forward_only else (args.views_per_rank * world if weak else args.views)
-    views = make_views(gs, cam, n_views)
+    views = make_views(gs, cam, n_views, group=args.views_per_rank if weak and not args.forward_only else None,
+                       world=world)
     grads = gs.FlatGrads(N, dev)
     mine = gs.shard_views(n_views, rank, world)
 
@@ -455,7 +463,7 @@ def main():
             "config": {"workload": workload,
                        "gaussians": N, "views_per_step": n_views, "width": W, "height": H, "tile": 16,
                        "log_scale_range": list(args.log_scale), "seed": 20240601,
-                       "view_set": "yaw (k-3.5)*1.5 deg, pitch ((3k mod n)-3.5)*0.6 deg about the origin: every gaussian "
+                       "view_set": "per rank: yaw (j-3.5)*1.5 deg, pitch ((3j mod n)-3.5)*0.6 deg about the origin for its n views j (+0.11 / +0.07 deg per rank): every gaussian "
                                    "stays visible in every view",
                        "n_visible": n_visible, "duplicates_D": int(D), "visited_D_star": d_star,
                        "max_tile_list": max_len, "pixels_per_thread": 4,
