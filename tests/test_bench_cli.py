@@ -42,3 +42,27 @@ def test_gpus_without_a_launcher_spawns_one_rank_per_gpu(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+
+
+def test_weak_scaling_view_sets_repeat_the_one_rank_pattern():
+    """Under weak scaling every rank renders the pattern of views the one-rank run renders (plus a small per-rank
+    offset), view k belonging to rank k % world: the per-rank workload does not change with the number of ranks."""
+    import math
+    import types
+    import numpy as np
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    gs = types.SimpleNamespace(View=lambda cam, R, t: R)
+    one = bench.make_views(gs, None, 8)
+    assert all(np.allclose(a, b) for a, b in zip(one, bench.make_views(gs, None, 8, group=8, world=1)))
+    for world in (2, 4, 8):
+        views = bench.make_views(gs, None, 8 * world, group=8, world=world)
+        assert len(views) == 8 * world
+        for rank in range(world):
+            mine = [views[k] for k in range(8 * world) if k % world == rank]
+            for j, R in enumerate(mine):
+                yaw = math.degrees(math.atan2(R[0, 2], R[2, 2]))      # R = Ry Rx
+                assert abs(yaw - ((j - 3.5) * 1.5 + 0.11 * rank)) < 1e-9
+                if rank == 0:
+                    assert np.allclose(R, one[j])
+        assert max(abs(math.degrees(math.atan2(R[0, 2], R[2, 2]))) for R in views) < 7.0
