@@ -407,6 +407,42 @@ SortedAux sorted_aux(gs_ctx *ctx, int32_t N) {
     return SortedAux{(int4 *)base, (float4 *)(base + n16), (float4 *)(base + 2 * n16), (uint2 *)(base + 3 * n16), nullptr};
 }
 
+// The tile count in its sorted form: depth sort over the low `bits` key bits, then the count in that order (counts[] and
+// the per-gaussian summaries in depth order), per-block partials and the total.  Keys and ids travel together, so a
+// sort over too few bits still counts correctly (D, max depth): only the order, and with it the lists, would be wrong.
+int sorted_count_launch(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t *depths, Grid grid,
+                        const float4 *rec, int32_t tile_size, float pixel_offset, int bits) {
+    int rc;
+    ulonglong2 *partials = (ulonglong2 *)((char *)ctx->total.p + 16);
+    const int32_t *perm = nullptr;
+    const uint32_t *depth_sorted = nullptr;
+    if ((rc = bin_depth_sort(ctx, N, depths, bits, &perm, &depth_sorted))) return rc;
+    ctx->sorted_bits = bits;
+    if ((rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 56))) return rc;
+    SortedAux aux = sorted_aux(ctx, N);
+    aux.depth_sorted = depth_sorted;
+    // records written by K1 (gs_ctx_use_records) carry the tile rect in their fourth quarter: one gathered line
+    const int4 *rect_src = rec && rec == ctx->ext_records ? nullptr : reinterpret_cast<const int4 *>(tiles_touched);
+    gs_prof_scope prof_(ctx, GS_K_COUNT);
+    if (rec) {
+        const CullBox cb{(float)tile_size, pixel_offset, ctx->cull_shrink ? 1 : 0};
+        hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_COUNT_SORTED>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
+                           perm, rect_src, depths, grid, rec, cb,
+                           (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr, aux);
+        // counts and keys are both in sorted order: D and the largest key among the gaussians that own a pair
+        hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
+                           (const uint32_t *)ctx->counts.p, reinterpret_cast<const int32_t *>(depth_sorted), partials);
+    } else {
+        hipLaunchKernelGGL(count_sorted_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N, perm,
+                           reinterpret_cast<const int4 *>(tiles_touched), depths, grid, (uint32_t *)ctx->counts.p,
+                           aux.info, partials, depth_sorted);
+    }
+    hipLaunchKernelGGL(count_total_kernel, dim3(1), dim3(COUNT_BLOCKS), 0, ctx->stream,
+                       (const ulonglong2 *)partials, (unsigned long long *)ctx->total.p);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 // rec == nullptr: the reference's rect semantics; otherwise pairs are culled with the box test.
 // Launches the count and the copy of (D, max depth) to pinned memory, and records count_event.
 // From ctx->sorted_count_from gaussians on (option sorted_count_from; SortedAux in binning_kernels.h) the depth
@@ -434,30 +470,10 @@ int bin_count_begin(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const 
     ulonglong2 *partials = (ulonglong2 *)((char *)ctx->total.p + 16);
     ctx->count_sorted = N >= ctx->sorted_count_from;
     if (ctx->count_sorted) {
-        const int32_t *perm = nullptr;
-        const uint32_t *depth_sorted = nullptr;
-        if ((rc = bin_depth_sort(ctx, N, depths, 32, &perm, &depth_sorted))) return rc;
-        if ((rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * 56))) return rc;
-        SortedAux aux = sorted_aux(ctx, N);
-        aux.depth_sorted = depth_sorted;
-        // records written by K1 (gs_ctx_use_records) carry the tile rect in their fourth quarter: one gathered line
-        const int4 *rect_src = rec && rec == ctx->ext_records ? nullptr : reinterpret_cast<const int4 *>(tiles_touched);
-        gs_prof_scope prof_(ctx, GS_K_COUNT);
-        if (rec) {
-            const CullBox cb{(float)tile_size, pixel_offset, ctx->cull_shrink ? 1 : 0};
-            hipLaunchKernelGGL(culled_pairs_kernel<PAIRS_COUNT_SORTED>, dim3(gs_div_up(N, 256)), dim3(256), 0, ctx->stream, N,
-                               perm, rect_src, depths, grid, rec, cb,
-                               (uint32_t *)ctx->counts.p, (const uint32_t *)nullptr, 0u, (uint2 *)nullptr, aux);
-            // (D only: the depth read beside a count belongs to another gaussian here, and max(depth) is not needed)
-            hipLaunchKernelGGL(count_sum_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N,
-                               (const uint32_t *)ctx->counts.p, depths, partials);
-        } else {
-            hipLaunchKernelGGL(count_sorted_kernel, dim3(COUNT_BLOCKS), dim3(SCAN_THREADS), 0, ctx->stream, N, perm,
-                               reinterpret_cast<const int4 *>(tiles_touched), depths, grid, (uint32_t *)ctx->counts.p,
-                               aux.info, partials, depth_sorted);
-        }
-        hipLaunchKernelGGL(count_total_kernel, dim3(1), dim3(COUNT_BLOCKS), 0, ctx->stream,
-                           (const ulonglong2 *)partials, (unsigned long long *)ctx->total.p);
+        // max(depth) is not known yet: sort the key bytes the last view counted on this ctx needed (all four the
+        // first time); bin_count_end checks the guess and bin_fill repeats sort + count with all bits if it was short
+        const int bits = ctx->depth_bits_hint > 0 ? (ctx->depth_bits_hint + 7) / 8 * 8 : 32;
+        if ((rc = sorted_count_launch(ctx, N, tiles_touched, depths, grid, rec, tile_size, pixel_offset, bits))) return rc;
     } else {
         if ((rc = gs_buf_reserve(ctx, &ctx->sorted_aux, (size_t)N * (rec ? 24 : 16)))) return rc;
         gs_prof_scope prof_(ctx, GS_K_COUNT);
@@ -506,6 +522,11 @@ int bin_count_end(gs_ctx *ctx, int64_t *D_host) {
     ctx->bin_N = N;
     ctx->bin_D = (int64_t)D;
     ctx->bin_max_depth = (uint32_t)ctx->total_host[1];
+    if (ctx->count_sorted) {      // was the guessed key width enough?  (bin_fill repeats sort + count if not)
+        const int need = bits_of(ctx->bin_max_depth) > 0 ? bits_of(ctx->bin_max_depth) : 1;
+        ctx->depth_bits_hint = need;
+        ctx->sorted_redo = need > ctx->sorted_bits;
+    }
     *D_host = (int64_t)D;
     return GS_OK;
 }
@@ -626,8 +647,12 @@ int bin_fill(gs_ctx *ctx, int32_t N, const int32_t *tiles_touched, const int32_t
     // K4a: gaussians into (u32(depth), id) order; only the bytes max(depth) occupies are sorted.  (Done already, and
     // the counts are in that order, when the count ran in its sorted form: perm stays NULL for the kernels below.)
     const int32_t *perm = nullptr;
-    if (!ctx->count_sorted)
+    if (!ctx->count_sorted) {
         if ((rc = bin_depth_sort(ctx, N, depths, bits_of(ctx->bin_max_depth), &perm))) return rc;
+    } else if (ctx->sorted_redo) {     // the count sorted fewer key bits than this view's depths occupy
+        if ((rc = sorted_count_launch(ctx, N, tiles_touched, depths, grid, rec, tile_size, pixel_offset, 32))) return rc;
+        ctx->sorted_redo = false;
+    }
 
     // K2': exclusive offsets of tiles-per-gaussian in depth order
     const int nblocks = gs_div_up(N, SCAN_TILE);

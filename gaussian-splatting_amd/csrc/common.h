@@ -89,6 +89,9 @@ struct gs_ctx {
     int32_t sorted_count_from = 2 << 20;
     bool cull_shrink = true;          // option cull_shrink_rect: culled count / emit walk the ellipse's own bounding box
     bool count_sorted = false;        // the pending / last count of this ctx ran in that form
+    int depth_bits_hint = 0;          // key bits the last sorted count on this ctx needed (0: none yet -> sort all 32)
+    int sorted_bits = 0;              // key bits the pending sorted count sorted
+    bool sorted_redo = false;         // ... which were too few: bin_fill sorts and counts again with all bits
     gs_buf sorted_aux;                // 56 B per gaussian in depth order: clipped rect + id, two record quarters, test mask
                                       // (the unsorted culled count keeps walked rect + test mask here, 24 B by gaussian id)
     int32_t bin_N = -1;
