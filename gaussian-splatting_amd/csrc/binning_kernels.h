@@ -87,8 +87,19 @@ __device__ __forceinline__ void wave_lds_sync() {
 // run that was open at the end of the previous window (`carry`, wave-uniform, 0 at the start).  One LDS round
 // trip and six DPP steps per window -- a binary search over the prefix array is six dependent LDS reads, and the
 // kernels that walk rects are bound by exactly that latency.  LDS operations of one wave execute in order.
+// Windows that lie inside ONE run -- most windows of a rect of hundreds of tiles -- take a shortcut: the run open at
+// the end of the previous window (`carry`) is asked for its end with a readlane, and if it covers this window too every
+// slot belongs to it (*uniform = true) with no LDS traffic at all.
 __device__ __forceinline__ uint32_t slot_owner(uint32_t *mark_row, int lane, uint32_t cnt, uint32_t first,
-                                               uint32_t sbase, uint32_t &carry) {
+                                               uint32_t sbase, uint32_t &carry, bool *uniform = nullptr) {
+    if (uniform) *uniform = false;
+    if (carry != 0u) {
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)(first + cnt), (int)(carry - 1u));
+        if (end >= sbase + 64u) {
+            if (uniform) *uniform = true;
+            return carry - 1u;
+        }
+    }
     mark_row[lane] = 0u;
     wave_lds_sync();
     if (cnt != 0u && first >= sbase && first < sbase + 64u) mark_row[first - sbase] = (uint32_t)lane + 1u;
@@ -345,6 +356,25 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
             aux.con[i] = con;
         }
     }
+    // Count passes with masks: a gaussian whose walked rect has at most SOLO tiles -- the typical one -- is tested by
+    // its own lane in a short loop (tiles in the rect's order: ty fastest), with no owner search, LDS atomics or
+    // per-window synchronisation; only the larger rects go through the cooperative walk below.
+    constexpr uint32_t SOLO = 16;
+    const uint32_t cnt_all = cnt;
+    uint32_t solo_bits = 0;
+    bool solo = false;
+    if (!CULL_EMIT && use_mask) {
+        solo = cnt > 0u && cnt <= SOLO;
+        const float2 hv = gs_box_halves(con);
+        int tx = x0, ty = y0;
+        for (uint32_t k = 0; k < SOLO; k++) {
+            const bool on = solo && k < cnt;
+            if (__ballot(on) == 0ull) break;
+            if (on && pair_may_contribute(geo, con, hv, tx, ty, cb)) solo_bits |= 1u << k;
+            if (++ty == y0 + h) { ty = y0; tx++; }
+        }
+        if (solo) cnt = 0u;           // nothing left for the cooperative walk
+    }
     const uint32_t inc = wave_inclusive_scan(cnt);
     const uint32_t first = inc - cnt;
     s_first[wave][lane] = first;
@@ -361,7 +391,9 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
     uint32_t carry = 0;
     for (uint32_t sbase = 0; sbase < wave_total; sbase += 64) {      // wave-uniform trip count
         const uint32_t sidx = sbase + lane;
-        const int lo = (int)slot_owner(s_mark[wave], lane, cnt, first, sbase, carry);
+        bool one_owner;
+        const int lo = (int)slot_owner(s_mark[wave], lane, cnt, first, sbase, carry, &one_owner);
+        if (one_owner && use_mask && s_cnt[wave][lo] <= 64u) one_owner = false;     // a run of exactly 64: it has a mask
         bool pass = false;
         int tx = 0, ty = 0;
         if (sidx < wave_total) {
@@ -373,10 +405,16 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
                 pass = (((local < 32u ? s_mlo[wave][lo] : s_mhi[wave][lo]) >> (local & 31u)) & 1u) != 0u;
             else
                 pass = pair_may_contribute(s_geo[wave][lo], s_con[wave][lo], s_half[wave][lo], tx, ty, cb);
-            if (!CULL_EMIT && pass) {
+            // (a window inside one run of more than 64 tiles is counted with a ballot below: 64 LDS atomics on one
+            // address are 64 serial operations)
+            if (!CULL_EMIT && pass && !one_owner) {
                 if (use_mask && s_cnt[wave][lo] <= 64u) atomicOr(local < 32u ? &s_mlo[wave][lo] : &s_mhi[wave][lo], 1u << (local & 31u));
                 else atomicAdd(&s_pass[wave][lo], 1u);
             }
+        }
+        if (!CULL_EMIT && one_owner) {       // the run covers the whole window, so it has more than 64 tiles: no mask
+            const uint32_t n_pass = (uint32_t)__popcll(__ballot(pass));
+            if (lane == 0) s_pass[wave][lo] += n_pass;
         }
         if (CULL_EMIT) {
             const unsigned long long m = __ballot(pass);
@@ -391,8 +429,8 @@ __device__ __forceinline__ void culled_pairs_body(int bid, int N, const int32_t 
     if (!CULL_EMIT) {
         __syncthreads();
         if (i < N) {
-            const bool small = use_mask && cnt <= 64u;
-            const uint32_t lo32 = s_mlo[wave][lane], hi32 = s_mhi[wave][lane];
+            const bool small = use_mask && cnt_all <= 64u;
+            const uint32_t lo32 = solo ? solo_bits : s_mlo[wave][lane], hi32 = solo ? 0u : s_mhi[wave][lane];
             counts[i] = small ? (uint32_t)(__popc(lo32) + __popc(hi32)) : s_pass[wave][lane];
             if (use_mask) aux.mask[i] = make_uint2(lo32, hi32);      // (mode 0: i is the gaussian id)
         }
