@@ -252,12 +252,26 @@ def main():
         c.profile(False)
         c.set_option("profile_mask", 0x7FFFFFFF)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # the step's collectives alone on the idle GPUs (same slices, same order, outside the timed region): how much of a
+    # multi-rank step is the gradient exchange -- it starts when the last view's K8 has run and the next step's K1 needs
+    # its result, so nearly all of it is exposed (Multi-GPU)
+    comm_alone = 0.0
+    if world > 1 and not args.forward_only:
+        grads.flat.zero_()
+        gs.grad_all_reduce_alone(pipe, grads)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(max(3, min(args.steps, 10))):
+            gs.grad_all_reduce_alone(pipe, grads)
+        barrier()
+        comm_alone = (time.perf_counter() - t1) / max(3, min(args.steps, 10))
+
+    t = torch.tensor([elapsed, comm_alone], dtype=torch.float64, device=dev)
     ones = torch.ones(1, dtype=torch.float32, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)      # what the process group really spans
-    elapsed = float(t.item())
+    elapsed, comm_alone = float(t[0].item()), float(t[1].item())
     ranks_seen = int(round(float(ones.item())))
     if ranks_seen != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the process group spans {ranks_seen} rank(s)")
@@ -470,6 +484,12 @@ def main():
                        "concurrent_views_per_rank": args.concurrent_views or gs.auto_lanes(pipe),
                        "lists": args.lists, "lists_note": LISTS_NOTE[args.lists], "ranks_seen": ranks_seen},
             "ranks_seen": ranks_seen,
+            "collective": None if world == 1 or args.forward_only else {
+                "what": "SUM all-reduce of the [N*59] fp32 gradient buffer, 4 ranges of SH gradients + 1 slice of the rest, "
+                        "as train_step issues them; timed alone on idle GPUs after the timed region, max over ranks",
+                "backend": backend, "bytes": N * 59 * 4, "alone_ms": round(comm_alone * 1e3, 3),
+                "algbw_GBps": round(N * 59 * 4 / comm_alone / 1e9, 1) if comm_alone > 0 else None,
+                "step_minus_collective_ms": round(ms_per_step - comm_alone * 1e3, 3)},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "other_lists": other_lists, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)

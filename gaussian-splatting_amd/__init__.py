@@ -7,7 +7,7 @@ from ._lib import GsError, LIB_PATH, SIGNATURES, load as load_library   # noqa: 
 from .api import (DeviceContext, GaussianSet, KernelLibrary, TileBinning, backward_pass, c_rasterize,   # noqa: F401
                   forward_pass, gpu_rasterize, match_gaus_to_tiles, rasterize, setup_gpu, view_stats)
 from .pipeline import (FlatGrads, flat_offsets, gaussian_chunks, Optimizer, REFERENCE_LEARNING_RATES, SplatPipeline, View, shard_views,   # noqa: F401
-                       all_reduce_sum, auto_lanes, train_step)
+                       all_reduce_sum, auto_lanes, grad_all_reduce_alone, train_step)
 from .io import (gaussians_from_point_cloud, knn_distances, load_data, load_gaussians, qvec2rotmat,   # noqa: F401
                  quat_to_rotmat, read_model, read_ply_vertices, save_gaussians, save_ply)
 from .functions import (focal_to_fov, get_jacobian_matrix, get_pixel, get_projection_matrix, get_view_matrix,   # noqa: F401

@@ -573,7 +573,19 @@ def _all_reduce(pipe, tensors, works):
     all_reduce_sum(pipe.ctx, tensors, works)
 
 
-BIG_VIEW_PAIRS = 32 << 20      # (gaussian, tile) pairs per view from which two lanes beat four (measured, 10 M / 4K)
+def grad_all_reduce_alone(pipe, grads, allreduce_chunks=4):
+    """The collectives of one train_step without its kernels (the same slices in the same order): what bench.py times
+    on an idle GPU to say how much of a multi-rank step is the gradient exchange."""
+    offs, _ = flat_offsets(pipe.N)
+    works = []
+    for g0, g1 in gaussian_chunks(pipe.N, allreduce_chunks):
+        _all_reduce(pipe, [grads.flat[offs[4] + 48 * g0:offs[4] + 48 * g1]], works)
+    _all_reduce(pipe, [grads.flat[:offs[4]]], works)
+    for w in works:
+        w.wait()
+
+
+BIG_VIEW_PAIRS = 32 << 20     # (gaussian, tile) pairs per view from which two lanes beat four (measured, 10 M / 4K)
 
 
 def auto_lanes(pipe):
