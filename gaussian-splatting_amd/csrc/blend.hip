@@ -612,6 +612,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // sub = which 16x16 block of the caller's tile (tiles larger than 16 share one list between their blocks) -- and
 // det_reduce_kernel adds up each gaussian's partials in list order.
 constexpr int DET_ROW = 12;    // floats per partial: 9 used, 48 bytes = three float4s
+constexpr int RED_ENTRIES = 4, RED_PLANE = 68;     // K7's row sums through LDS (see the kernel)
 template <bool DET>
 __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_kernel(QuadArgs a,
                                                                          const int32_t *__restrict__ n_contrib,
@@ -629,6 +630,12 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     if (a.W < 0) s_pad_[threadIdx.x] = 0u;
 #endif
 
+#ifndef GS_K7_ROWSUM_DPP
+    // row sums through LDS: RED_ENTRIES entries x 3 values x 64 lanes, planes 68 floats apart (the 16-byte pieces
+    // the 16 lanes of a quarter-wave read then fall into 16 different groups of four banks)
+    __shared__ __align__(16) float s_red_[QUAD_WAVES][RED_ENTRIES * 3 * RED_PLANE];
+#endif
+
     const int wv = threadIdx.x >> 6;
     const int slot = blockIdx.x * QUAD_WAVES + wv;
     if (slot >= a.ntiles) return;            // whole wave; no workgroup barrier is used below
@@ -636,6 +643,10 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     GS_STAMP_BEGIN();
     float4 *s_geo = s_rec_[wv][0], *s_con = s_rec_[wv][1], *s_rgb = s_rec_[wv][2];
     const float *s_flat = reinterpret_cast<const float *>(s_rec_[wv]);
+#ifndef GS_K7_ROWSUM_DPP
+    float *s_park = reinterpret_cast<float *>(s_rec_[wv]);
+    float *s_red = s_red_[wv];
+#endif
     unsigned *s_qm = s_qm_[wv];
     const int tx = tile / a.tiles_y, ty = tile % a.tiles_y;
     const int lane = threadIdx.x & 63;
@@ -648,9 +659,35 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
 
     // lane 15 of row r finishes gradient words r and 4+r; the factors undo the log2 pre-scaling
     // (d power/d(.) = ln2 * d power2/d(.)) and map (a',b',c') back to the conic (A,B,C)
+#ifdef GS_K7_ROWSUM_DPP
     const int row = lane >> 4;
     const float sc0 = row < 2 ? LN2 : (row == 2 ? -0.5f : -1.0f);
     const float sc1 = row == 0 ? -0.5f : 1.0f;
+#else
+    // The 16-lane row sums of up to RED_ENTRIES entries are formed together: every lane parks its three partial
+    // values of an entry in s_red, and once RED_ENTRIES entries are parked (or the batch ends) lane
+    // (value v, entry e, row r) = (lane >> 4, (lane >> 2) & 3, lane & 3) adds the 16 floats of its row -- four
+    // 16-byte reads and 15 adds for a quarter of an entry's 12 sums, where the DPP form spent 15 DPP instructions
+    // (each twice the issue cost of a plain one) and 5 waits per entry.  v = 0, 1: gradient words r and 4 + r of
+    // entry e; v = 2: the row's share of word 8, whose four rows sit in four neighbouring lanes.
+    const int f_v = lane >> 4, f_e = (lane >> 2) & 3, f_r = lane & 3;
+    const float4 *f_src = reinterpret_cast<const float4 *>(s_red + (f_e * 3 + (f_v < 3 ? f_v : 0)) * RED_PLANE + f_r * 16);
+    const float f_scale = f_v == 0 ? (f_r < 2 ? LN2 : (f_r == 2 ? -0.5f : -1.0f)) : (f_v == 1 ? (f_r == 0 ? -0.5f : 1.0f) : 1.0f);
+    float *f_dst = s_park + f_v * 256 + (f_v < 2 ? f_r : 0);        // + 4 * (the entry's slot in the batch)
+    auto sum_rows = [&](int n_parked, unsigned slots) {              // slots: byte k = batch slot of parked entry k
+        wave_lds_fence();
+        if (f_v < 3 && f_e < n_parked) {
+            const float4 q0 = f_src[0], q1 = f_src[1], q2 = f_src[2], q3 = f_src[3];
+            float t = (((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w))) +
+                      (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
+            float t4 = t + dpp_term<0xB1, 0xF>(t);                   // quad_perm [1,0,3,2]
+            t4 += dpp_term<0x4E, 0xF>(t4);                           // quad_perm [2,3,0,1]: the four rows of word 8
+            t = f_v == 2 ? t4 : t;
+            f_dst[4 * ((slots >> (8 * f_e)) & 0xffu)] = t * f_scale;
+        }
+        wave_lds_fence();                                            // before the next entries are parked
+    };
+#endif
 
     // per pixel: transmittance T (walked backwards by division), dL/dpixel, and the running
     // scalar s = T_final*(bg.dL) + sum_{k behind} w_k (c_k.dL)  (what sits behind the current
@@ -719,6 +756,10 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
         for (int k = 0; k < 4; k++) live[k] = __ballot((myq >> k) & 1u);
 
         unsigned long long touched = 0ull;   // wave-uniform: entries that received a gradient
+#ifndef GS_K7_ROWSUM_DPP
+        int n_parked = 0;                    // wave-uniform: entries whose partial values wait in s_red
+        unsigned parked_slots = 0u;
+#endif
         for (unsigned long long rem = live[0] | live[1] | live[2] | live[3]; rem != 0ull;) {
             const int j = 63 - __builtin_clzll(rem);
             rem &= ~(1ull << j);
@@ -790,10 +831,11 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
             swap32(g_C, g_r);  const float w2 = g_C + g_r;
             swap32(g_o, g_g);  const float w3 = g_o + g_g;
             float u0 = w0, u1 = w1, u2 = w2, u3 = w3;
+            touched |= 1ull << j;
+#ifdef GS_K7_ROWSUM_DPP
             swap16(u0, u1); const float x0 = row_sum_to_lane15(u0 + u1);   // rows: d cx, d cy, d a', d b'
             swap16(u2, u3); const float x1 = row_sum_to_lane15(u2 + u3);   // rows: d c', d o, d r, d g
             g_b = wave_sum_to_lane63(g_b);
-            touched |= 1ull << j;
             if ((lane & 15) == 15) {
                 reinterpret_cast<float *>(&s_geo[j])[lane >> 4] = x0 * sc0;
                 reinterpret_cast<float *>(&s_con[j])[lane >> 4] = x1 * sc1;
@@ -802,7 +844,29 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                 s_rgb[j].x = g_b;
                 if (DET) s_rgb[j].y = __int_as_float(idx);     // the colour is dead: keep the entry's list position
             }
+#else
+            swap16(u0, u1);                                    // rows: d cx, d cy, d a', d b'
+            swap16(u2, u3);                                    // rows: d c', d o, d r, d g
+            float *park = s_red + n_parked * (3 * RED_PLANE) + lane;
+            park[0] = u0 + u1;
+            park[RED_PLANE] = u2 + u3;
+            park[2 * RED_PLANE] = g_b;
+            if (DET && lane == 63) s_rgb[j].y = __int_as_float(idx);       // the colour is dead: keep the entry's list position
+            parked_slots |= (unsigned)j << (8 * n_parked);
+            if (++n_parked == RED_ENTRIES) {
+                sum_rows(RED_ENTRIES, parked_slots);
+                n_parked = 0;
+                parked_slots = 0u;
+            }
+#endif
         }
+#ifndef GS_K7_ROWSUM_DPP
+        if (n_parked) {
+            sum_rows(n_parked, parked_slots);
+            n_parked = 0;
+            parked_slots = 0u;
+        }
+#endif
         wave_lds_fence();
         // flush: one 64-byte row per gaussian, 4 rows per wave-instruction, lanes 0..8 of each
         // 16-lane group active -> one memory-side atomic request per (tile, gaussian)
