@@ -612,7 +612,10 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // sub = which 16x16 block of the caller's tile (tiles larger than 16 share one list between their blocks) -- and
 // det_reduce_kernel adds up each gaussian's partials in list order.
 constexpr int DET_ROW = 12;    // floats per partial: 9 used, 48 bytes = three float4s
-constexpr int RED_ENTRIES = 4, RED_PLANE = 68;     // K7's row sums through LDS (see the kernel)
+#ifndef GS_RED_ENTRIES
+#define GS_RED_ENTRIES 4
+#endif
+constexpr int RED_ENTRIES = GS_RED_ENTRIES, RED_PLANE = 68;     // K7's row sums through LDS (see the kernel)
 template <bool DET>
 __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_kernel(QuadArgs a,
                                                                          const int32_t *__restrict__ n_contrib,
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
                                                                          float *__restrict__ grad_rows,
                                                                          float *__restrict__ det_out, int64_t det_D) {
     // per wave: 64 staged records of 12 words (geo | con | rgb).  Once entry j has been processed
-    // its record is dead, so lane 63 parks the 9 reduced gradients in place: geo.xyzw, con.xyzw,
+    // its record is dead, so its 9 reduced gradients are parked in place: geo.xyzw, con.xyzw,
     // rgb.x; rgb.w keeps the gaussian id for the flush.
     __shared__ float4 s_rec_[QUAD_WAVES][3][64];
     __shared__ unsigned s_qm_[QUAD_WAVES][64];
@@ -657,9 +660,9 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     const float xlo = (float)X0 - off, ylo = (float)Y0 - off;
     const int2 rg = a.ranges[(tx >> a.shift) * a.list_tiles_y + (ty >> a.shift)];
 
-    // lane 15 of row r finishes gradient words r and 4+r; the factors undo the log2 pre-scaling
-    // (d power/d(.) = ln2 * d power2/d(.)) and map (a',b',c') back to the conic (A,B,C)
-#ifdef GS_K7_ROWSUM_DPP
+    // the factors undo the log2 pre-scaling (d power/d(.) = ln2 * d power2/d(.)) and map (a',b',c') back to the
+    // conic (A,B,C)
+#ifdef GS_K7_ROWSUM_DPP    // the round-2 form, kept for A/B: lane 15 of row r finishes gradient words r and 4+r with DPP
     const int row = lane >> 4;
     const float sc0 = row < 2 ? LN2 : (row == 2 ? -0.5f : -1.0f);
     const float sc1 = row == 0 ? -0.5f : 1.0f;
@@ -668,8 +671,10 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
     // values of an entry in s_red, and once RED_ENTRIES entries are parked (or the batch ends) lane
     // (value v, entry e, row r) = (lane >> 4, (lane >> 2) & 3, lane & 3) adds the 16 floats of its row -- four
     // 16-byte reads and 15 adds for a quarter of an entry's 12 sums, where the DPP form spent 15 DPP instructions
-    // (each twice the issue cost of a plain one) and 5 waits per entry.  v = 0, 1: gradient words r and 4 + r of
-    // entry e; v = 2: the row's share of word 8, whose four rows sit in four neighbouring lanes.
+    // (each twice the issue cost of a plain one) and 5 waits per entry: 0.425 -> 0.375 ms per 1080p view, same box.
+    // (2 or 3 entries per round: 0.395 / 0.39 ms; moving what is linear in the sums -- the centre gradient, the
+    // division by the opacity -- behind the sums as well: no change, dropped.)  v = 0, 1: gradient words r and 4 + r
+    // of entry e; v = 2: the row's share of word 8, whose four rows sit in four neighbouring lanes.
     const int f_v = lane >> 4, f_e = (lane >> 2) & 3, f_r = lane & 3;
     const float4 *f_src = reinterpret_cast<const float4 *>(s_red + (f_e * 3 + (f_v < 3 ? f_v : 0)) * RED_PLANE + f_r * 16);
     const float f_scale = f_v == 0 ? (f_r < 2 ? LN2 : (f_r == 2 ? -0.5f : -1.0f)) : (f_v == 1 ? (f_r == 0 ? -0.5f : 1.0f) : 1.0f);
@@ -819,9 +824,9 @@ __global__ __launch_bounds__(64 * QUAD_WAVES, GS_BWD_WAVES) void blend_bwd_quad_
 #ifdef GS_STAMPS
             if (lane == 0) atomicAdd(&gs_valid_hist[32 - __builtin_clz((unsigned)n_valid_px)], 1ull);
 #endif
-            // 9 wave-wide sums in 6 lane swaps + 6 adds + 14 DPP adds instead of 54 DPP adds (a DPP add
-            // issues in 4 cycles, twice a plain VALU op): permlane32/16 swaps fold two values per
-            // instruction, leaving each 16-lane row with its own pair of values to finish.
+            // 9 wave-wide sums: permlane32/16 swaps fold two values per instruction (6 swaps + 6 adds), leaving
+            // each 16-lane row with its own pair of values to finish, and word 8 on all 64 lanes; those 16-lane
+            // sums are formed through LDS, RED_ENTRIES entries at a time (sum_rows above).
             // d power2/d cx = 2a' dx + b' dy and d power2/d cy = 2c' dy + b' dx, with (a', b', c') uniform
             float g_cx = __builtin_fmaf(co.x + co.x, s_x, co.y * s_y);
             float g_cy = __builtin_fmaf(co.z + co.z, s_y, co.y * s_x);
