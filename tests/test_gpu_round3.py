@@ -384,3 +384,57 @@ def test_sorted_count_form_gives_the_same_lists(gpu_ctx):
             for x, y in zip(a[1:], b[1:]):
                 assert (x is None and y is None) or np.array_equal(x, y), k
     assert sum(a[0] for a in ref) > 100_000
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 66, 67, 130])
+@pytest.mark.parametrize("det", [False, True])
+def test_k7_row_sums_for_every_remainder_of_parked_entries(gpu_ctx, n, det):
+    """K7 forms the 16-lane row sums of four entries at a time through LDS (csrc/blend.hip, sum_rows) and finishes a
+    batch with one to three parked entries: n faint gaussians that all cover the whole 48x32 frame (nothing
+    terminates, every entry is reduced in every tile) make each tile's list exactly n entries long, so the last
+    round of every 64-entry batch holds n mod 4 (and (n - 64) mod 4, ...) entries.  All nine outputs against fp64
+    autograd of the oracle blend told the device's decisions, 1e-4 of the largest entry; with and without the
+    ordered (deterministic) reduction."""
+    import torch
+    import gsplat_amd as gs
+    from oracle import ref_np, ref_torch
+    W, H = 48, 32
+    rng = np.random.default_rng(400 + n)
+    cen = np.stack([rng.uniform(4, W - 4, n), rng.uniform(4, H - 4, n)], 1).astype(np.float32)
+    s = rng.uniform(25.0, 60.0, (n, 2))
+    th = rng.uniform(0, np.pi, n)
+    con = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        Rm = np.array([[np.cos(th[i]), -np.sin(th[i])], [np.sin(th[i]), np.cos(th[i])]])
+        inv = np.linalg.inv(Rm @ np.diag(s[i] ** 2) @ Rm.T)
+        con[i] = inv[0, 0], inv[0, 1], inv[1, 1]
+    opa = rng.uniform(0.02, 0.05 if n > 8 else 0.4, n).astype(np.float32)     # 130 of them still leave T > 1e-4
+    col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    rs = [W, H]
+    tt = np.tile(np.array([[[0, 0], [W // 16, H // 16]]], dtype=np.int32), (n, 1, 1))
+    dep = rng.permutation(n).astype(np.int32) + 1
+    dev = gpu_ctx.device
+    t_ = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    gpu_ctx.set_option("deterministic_backward", 1 if det else 0)
+    try:
+        b = gs.match_gaus_to_tiles(gpu_ctx, None, None, tt, np.ones(n), dep, result_size=rs, tile_size=16)
+        bg = np.array([0.3, 0.1, 0.2])
+        bg3 = gs.api._bg3(bg)
+        img, nc, tf = gs.api.blend_forward(gpu_ctx, t_(cen), t_(col), t_(opa), t_(con), b, bg3, 0.5)
+        vals, ranges = b.vals.cpu().numpy(), b.ranges.cpu().numpy()
+        assert np.all(ranges[:, 1] - ranges[:, 0] == n)
+        assert int((nc.cpu().numpy() & 0x7fffffff).min()) == n            # every pixel walked the whole list
+        forced = ref_np.device_decisions(cen, con, opa, vals, ranges, rs, 16, 0.5, nc.cpu().numpy())
+        p = [torch.tensor(a.astype(np.float64), requires_grad=True) for a in (cen, col, opa, con)]
+        ref_img = ref_torch.blend(p[0], p[1], p[2], p[3], vals, ranges, rs, 16, bg, 0.5, forced=forced)
+        wimg = np.random.default_rng(9).normal(size=(W, H, 3)).astype(np.float32)
+        (ref_img * torch.tensor(wimg, dtype=torch.float64)).sum().backward()
+        got = gs.api.blend_backward(gpu_ctx, t_(cen), t_(col), t_(opa), t_(con), b, bg3, 0.5, nc, tf, t_(wimg))
+        for g_, want, what in zip(got, (p[0].grad, p[3].grad, p[2].grad, p[1].grad), ("centers", "conics", "opacity", "colors")):
+            gnp = g_.cpu().numpy().astype(np.float64)
+            ref = want.numpy()
+            assert np.all(np.isfinite(gnp)), what
+            scale = np.abs(ref).max()
+            assert scale > 0 and np.abs(gnp - ref).max() <= 1e-4 * scale, (what, n, np.abs(gnp - ref).max() / scale)
+    finally:
+        gpu_ctx.set_option("deterministic_backward", 0)
